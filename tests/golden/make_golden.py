@@ -1,0 +1,215 @@
+"""Generate the golden parity fixtures by running the REFERENCE implementation on CPU.
+
+Run in the build container only (needs /root/reference, which never travels to the GPU box):
+
+    PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_golden.py
+
+The reference module ``model/architecture/aagcn/agcn.py`` is loaded by file path
+(``import model`` fails on missing optional deps) with the one shim
+SURVEY.md F3 calls for: ``unit_gcn.forward`` does ``self.A.cuda(x.get_device())``
+(agcn.py:94), which raises on CPU tensors, so ``Tensor.cuda`` is made an identity
+in THIS process only.  Nothing from the reference is copied: the fixtures hold
+inputs/outputs (data), and parameters are regenerated from a seeded recipe
+(``oracle.agcn_oracle.randomized_state``).
+"""
+import importlib.util
+import os
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+REF = '/root/reference'
+sys.path.insert(0, ROOT)
+sys.dont_write_bytecode = True
+
+from oracle import agcn_oracle as orc  # noqa: E402
+
+
+def load_reference():
+    sys.path.insert(0, REF)          # for ``graph.*`` resolved by the reference's import_class
+    # make sure the reference's own graph package wins inside this process
+    for k in [k for k in sys.modules if k == 'graph' or k.startswith('graph.')]:
+        del sys.modules[k]
+    spec = importlib.util.spec_from_file_location(
+        'ref_agcn', os.path.join(REF, 'model/architecture/aagcn/agcn.py'))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    torch.Tensor.cuda = lambda self, *a, **k: self      # F3 shim (oracle process only)
+    return mod
+
+
+def ref_graph(v):
+    import importlib
+    name = {25: 'graph.ntu_rgb_d', 18: 'graph.kinetics'}[v]
+    return importlib.import_module(name).Graph(labeling_mode='spatial').A
+
+
+def sample_idx(numel, k=64):
+    return np.unique(np.linspace(0, numel - 1, num=min(k, numel)).astype(np.int64))
+
+
+def pack_grads(out, named_params, prefix='g.', full_limit=40000):
+    for name, p in named_params:
+        g = p.grad.detach().numpy().astype(np.float32)
+        out[prefix + name + '.norm'] = np.float64(np.linalg.norm(g.astype(np.float64)))
+        out[prefix + name + '.absmax'] = np.float32(np.abs(g).max())
+        if g.size <= full_limit:
+            out[prefix + name] = g
+        else:
+            idx = sample_idx(g.size, 256)
+            out[prefix + name + '.idx'] = idx
+            out[prefix + name + '.samples'] = g.reshape(-1)[idx]
+
+
+UNIT_CASES = [
+    # name, cin, cout, stride, residual, T, V, seed, stress
+    ('u_3_64_s1_v25', 3, 64, 1, False, 16, 25, 101, 1.0),
+    ('u_64_64_s1_v25', 64, 64, 1, True, 16, 25, 102, 1.0),
+    ('u_64_64_s1_v25_stress', 64, 64, 1, True, 32, 25, 103, 6.0),
+    ('u_64_128_s2_v25', 64, 128, 2, True, 16, 25, 104, 1.0),
+    ('u_128_256_s2_v25', 128, 256, 2, True, 16, 25, 105, 4.0),
+    ('u_64_64_s1_v18', 64, 64, 1, True, 16, 18, 106, 4.0),
+    ('u_64_128_s2_v18_oddT', 64, 128, 2, True, 15, 18, 107, 1.0),
+]
+
+
+def unit_inputs(cin, cout, stride, t, v, seed, n=2):
+    rng = np.random.default_rng(seed + 5000)
+    x = rng.standard_normal((n, cin, t, v)).astype(np.float32)
+    tout = (t + 2 * 4 - 9) // stride + 1
+    r = rng.standard_normal((n, cout, tout, v)).astype(np.float32)
+    return x, r
+
+
+def make_unit(ref, name, cin, cout, stride, residual, t, v, seed, stress):
+    A = ref_graph(v)
+    unit = ref.TCN_GCN_unit(cin, cout, A, stride=stride, residual=residual)
+    shapes = orc.unit_param_shapes('', cin, cout, v, stride, residual)
+    assert set(shapes) == set(unit.state_dict().keys()), \
+        (set(shapes) ^ set(unit.state_dict().keys()))
+    sd = orc.randomized_state(shapes, seed, stress=stress)
+    unit.load_state_dict(sd)
+    xn, rn = unit_inputs(cin, cout, stride, t, v, seed)
+    out = {}
+    # eval-mode forward first (running stats untouched)
+    unit.eval()
+    with torch.no_grad():
+        out['y_eval'] = unit(torch.from_numpy(xn)).numpy()
+    # train-mode forward/backward
+    unit.train()
+    x = torch.from_numpy(xn).requires_grad_(True)
+    y = unit(x)
+    loss = (y * torch.from_numpy(rn)).sum()
+    loss.backward()
+    out['y'] = y.detach().numpy()
+    out['dx'] = x.grad.numpy()
+    out['loss'] = np.float64(loss.item())
+    pack_grads(out, unit.named_parameters())
+    for k, b in unit.state_dict().items():
+        if k.endswith(('running_mean', 'running_var')):
+            out['buf.' + k] = b.numpy().copy()
+    # diagnostic: spread of the adaptive-adjacency logits of subset 0 (recorded)
+    with torch.no_grad():
+        sdd = {k: v_.clone() for k, v_ in sd.items()}
+        _, s, _ = orc.adaptive_adjacency(torch.from_numpy(xn), sdd, 'gcn1.', torch.from_numpy(A).float(), 0)
+        out['meta.std_S'] = np.float32(s.std().item())
+    out['meta'] = np.array([cin, cout, stride, int(residual), t, v, seed], dtype=np.int64)
+    out['meta.stress'] = np.float32(stress)
+    np.savez_compressed(os.path.join(HERE, name + '.npz'), **out)
+    print(f'{name}: y {out["y"].shape} |y|max {np.abs(out["y"]).max():.3f} std(S) {out["meta.std_S"]:.3f}')
+
+
+def model_inputs(n, v, num_class, seed, t=300):
+    rng = np.random.default_rng(seed + 7000)
+    x = rng.standard_normal((n, 3, t, v, 2)).astype(np.float32)
+    lab = rng.integers(0, num_class, size=(n,)).astype(np.int64)
+    return x, lab
+
+
+MODEL_CASES = [
+    # name, batch, V, num_class, graph, seed, stress, T
+    ('m_ntu_b1', 1, 25, 60, 'graph.ntu_rgb_d.Graph', 201, 3.0, 300),
+    ('m_ntu_b2', 2, 25, 60, 'graph.ntu_rgb_d.Graph', 202, 3.0, 300),
+    ('m_kin_b2_t64', 2, 18, 400, 'graph.kinetics.Graph', 203, 3.0, 64),
+]
+
+
+def make_model(ref, name, n, v, num_class, graph, seed, stress, t):
+    model = ref.Model(num_class=num_class, num_point=v, num_person=2, graph=graph,
+                      graph_args=dict(labeling_mode='spatial'))
+    shapes = orc.model_param_shapes(num_class, v)
+    assert set(shapes) == set(model.state_dict().keys())
+    sd = orc.randomized_state(shapes, seed, stress=stress)
+    model.load_state_dict(sd)
+    xn, lab = model_inputs(n, v, num_class, seed, t)
+    out = {}
+    model.eval()
+    with torch.no_grad():
+        out['logits_eval'] = model(torch.from_numpy(xn)).numpy()
+    model.train()
+    logits = model(torch.from_numpy(xn))
+    loss = torch.nn.functional.cross_entropy(logits, torch.from_numpy(lab))
+    loss.backward()
+    out['logits'] = logits.detach().numpy()
+    out['loss'] = np.float64(loss.item())
+    pack_grads(out, model.named_parameters(), full_limit=2000)
+    out['meta'] = np.array([n, v, num_class, seed, t], dtype=np.int64)
+    out['meta.stress'] = np.float32(stress)
+    np.savez_compressed(os.path.join(HERE, name + '.npz'), **out)
+    print(f'{name}: loss {out["loss"]:.6f} logits absmax {np.abs(out["logits"]).max():.3f}')
+
+
+def make_train_trace(ref):
+    """3 SGD steps as reference utils/processor.py:696-703 does them: zero_grad, backward,
+    clip_grad_norm_(1.0), SGD(momentum .9, nesterov, wd 1e-4) step; lr 0.1 (train_joint.yaml:29-39)."""
+    n, v, num_class, seed = 2, 25, 60, 301
+    model = ref.Model(num_class=num_class, num_point=v, num_person=2, graph='graph.ntu_rgb_d.Graph',
+                      graph_args=dict(labeling_mode='spatial'))
+    sd = orc.randomized_state(orc.model_param_shapes(num_class, v), seed, stress=3.0)
+    model.load_state_dict(sd)
+    model.train()
+    opt = torch.optim.SGD(model.parameters(), lr=0.1, momentum=0.9, nesterov=True, weight_decay=1e-4)
+    losses, gnorms = [], []
+    for step in range(3):
+        xn, lab = model_inputs(n, v, num_class, seed + step, 300)
+        logits = model(torch.from_numpy(xn))
+        loss = torch.nn.functional.cross_entropy(logits, torch.from_numpy(lab))
+        opt.zero_grad()
+        loss.backward()
+        gn = torch.nn.utils.clip_grad_norm_(model.parameters(), 1.0)
+        opt.step()
+        losses.append(loss.item())
+        gnorms.append(float(gn))
+    out = {'losses': np.array(losses, dtype=np.float64), 'grad_norms': np.array(gnorms, dtype=np.float64)}
+    for k in ('fc.weight', 'l1.gcn1.PA', 'l5.tcn1.conv.weight', 'l10.gcn1.conv_d.2.weight', 'l1.gcn1.bn.running_var'):
+        t = model.state_dict()[k].numpy().astype(np.float64)
+        out['final.' + k + '.sum'] = np.float64(t.sum())
+        out['final.' + k + '.norm'] = np.float64(np.linalg.norm(t))
+        idx = sample_idx(t.size, 32)
+        out['final.' + k + '.idx'] = idx
+        out['final.' + k + '.samples'] = t.reshape(-1)[idx].astype(np.float32)
+    out['meta'] = np.array([n, v, num_class, seed], dtype=np.int64)
+    np.savez_compressed(os.path.join(HERE, 'train_trace_ntu_b2.npz'), **out)
+    print('train trace losses', losses, 'gnorms', gnorms)
+
+
+def make_graphs():
+    out = {}
+    for v in (25, 18):
+        out[f'A_v{v}'] = np.asarray(ref_graph(v), dtype=np.float64)
+    np.savez_compressed(os.path.join(HERE, 'graphs.npz'), **out)
+
+
+if __name__ == '__main__':
+    torch.manual_seed(0)
+    torch.set_num_threads(8)
+    ref = load_reference()
+    make_graphs()
+    for case in UNIT_CASES:
+        make_unit(ref, *case)
+    for case in MODEL_CASES:
+        make_model(ref, *case)
+    make_train_trace(ref)
