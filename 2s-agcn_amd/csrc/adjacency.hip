@@ -1,0 +1,316 @@
+// Adaptive adjacency of unit_gcn (reference agcn.py:95,99-102):
+//   S_i[u,v]  = (1/K) sum_{c',t} theta_i[c',t,u] * phi_i[c',t,v],  K = Ci*T
+//   P_i[:,v]  = softmax_u(S_i[:,v])               (normalised over the FIRST joint index)
+//   A^_i      = P_i + A_i + PA_i                   (AGCN)     |  PA_i + alpha*P_i  (AAGCN)
+// theta/phi arrive as one tensor TP (N, 6*Ci, T*V) produced by the 1x1 channel contraction, rows
+// ordered [theta_0 | phi_0 | theta_1 | phi_1 | theta_2 | phi_2].
+//
+// The (c',t) contraction is a 25x25xK product per (sample, subset): K is split over frame tiles
+// (one workgroup each, matrix cores), partial VxV tiles go to a slab and the tiny finalize kernel adds
+// them in a fixed order, so results are bitwise reproducible.
+#include "agcn_common.h"
+
+namespace {
+
+constexpr int SC_CK = 16;   // theta/phi channels staged per LDS chunk
+
+__global__ void __launch_bounds__(256)
+scores_fwd_kernel(const float* __restrict__ tp, float* __restrict__ spart, int N, int Ci, int T, int V, int tt,
+                  int ntiles) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int ttv = tt * V;
+  float* Th = smem;                  // [SC_CK*tt][V]
+  float* Ph = smem + SC_CK * ttv;    // [SC_CK*tt][V]
+  float* red = Ph + SC_CK * ttv;     // [4][V*V]
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int lr = lane & 31, h = lane >> 5;
+  const int n = blockIdx.x / ntiles, tile = blockIdx.x - n * ntiles;
+  const int i = blockIdx.y;
+  const int t0 = tile * tt;
+  const int nvalid = min(tt, T - t0) * V;
+  const long P = (long)T * V;
+  const float* th_base = tp + ((long)n * 6 * Ci + (long)i * 2 * Ci) * P + (long)t0 * V;
+  const float* ph_base = th_base + (long)Ci * P;
+  f32x16 d;
+#pragma unroll
+  for (int j = 0; j < 16; ++j) d[j] = 0.f;
+  const int lc = min(lr, V - 1);
+  for (int c0 = 0; c0 < Ci; c0 += SC_CK) {
+    __syncthreads();
+    for (int cl = wave; cl < SC_CK; cl += 4) {
+      const bool ok = (c0 + cl) < Ci;
+      const float* s1 = th_base + (long)(c0 + (ok ? cl : 0)) * P;
+      const float* s2 = ph_base + (long)(c0 + (ok ? cl : 0)) * P;
+      for (int q = lane; q < ttv; q += 64) {
+        const bool v = ok && q < nvalid;
+        Th[cl * ttv + q] = v ? s1[q] : 0.f;
+        Ph[cl * ttv + q] = v ? s2[q] : 0.f;
+      }
+    }
+    __syncthreads();
+    const int npairs = (SC_CK * tt) >> 1;   // SC_CK even
+    for (int it = wave; it < npairs; it += 4) {
+      const int row = 2 * it + h;
+      float av = Th[row * V + lc];
+      float bv = Ph[row * V + lc];
+      av = (lr < V) ? av : 0.f;
+      bv = (lr < V) ? bv : 0.f;
+      d = mfma32(av, bv, d);
+    }
+  }
+  const int VV = V * V;
+#pragma unroll
+  for (int j = 0; j < 16; ++j) {
+    const int u = mfma_row(j, h);
+    if (u < V && lr < V) red[wave * VV + u * V + lr] = d[j];
+  }
+  __syncthreads();
+  float* dst = spart + (((long)n * 3 + i) * ntiles + tile) * VV;
+  for (int e = tid; e < VV; e += 256) dst[e] = red[e] + red[VV + e] + red[2 * VV + e] + red[3 * VV + e];
+}
+
+// one 64-lane wave per (n, i): sum the partial tiles, scale, column softmax, add the static graph terms
+__global__ void __launch_bounds__(64)
+adj_finalize_kernel(const float* __restrict__ spart, const float* __restrict__ A, const float* __restrict__ PA,
+                    const float* __restrict__ alpha, float* __restrict__ Pout, float* __restrict__ adj, int V,
+                    int ntiles, float inv_k) {
+  __shared__ float S[32 * 32];
+  const int ni = blockIdx.x, i = ni % 3;
+  const int VV = V * V, lane = threadIdx.x;
+  const float* src = spart + (long)ni * ntiles * VV;
+  for (int e = lane; e < VV; e += 64) {
+    float s = 0.f;
+    for (int t = 0; t < ntiles; ++t) s += src[(long)t * VV + e];
+    S[e] = s * inv_k;
+  }
+  __syncthreads();
+  if (lane < V) {
+    const int v = lane;
+    float mx = -INFINITY;
+    for (int u = 0; u < V; ++u) mx = fmaxf(mx, S[u * V + v]);
+    float sum = 0.f;
+    for (int u = 0; u < V; ++u) {
+      const float e = expf(S[u * V + v] - mx);
+      S[u * V + v] = e;
+      sum += e;
+    }
+    const float inv = 1.f / sum;
+    const float al = alpha ? alpha[0] : 1.f;
+    for (int u = 0; u < V; ++u) {
+      const float p = S[u * V + v] * inv;
+      const int e = u * V + v;
+      Pout[(long)ni * VV + e] = p;
+      // AGCN: P + A + PA (agcn.py:95,102); AAGCN: PA + alpha*P (aagcn.py:173), A = null
+      adj[(long)ni * VV + e] = al * p + (A ? A[i * VV + e] : 0.f) + PA[i * VV + e];
+    }
+  }
+}
+
+// per (n,i): dadj = sum of slot partials; dS = P * (dP - sum_u P dP) / K with dP = alpha*dadj
+__global__ void __launch_bounds__(64)
+adj_bwd_kernel(const float* __restrict__ dpart, const float* __restrict__ P, const float* __restrict__ alpha,
+               float* __restrict__ dadj, float* __restrict__ dS, float* __restrict__ dalpha_part, int V, int nslots,
+               float inv_k) {
+  __shared__ float D[32 * 32];
+  __shared__ float dal[32];
+  const int ni = blockIdx.x;
+  const int VV = V * V, lane = threadIdx.x;
+  const float* src = dpart + (long)ni * nslots * VV;
+  for (int e = lane; e < VV; e += 64) {
+    float s = 0.f;
+    for (int t = 0; t < nslots; ++t) s += src[(long)t * VV + e];
+    D[e] = s;
+    dadj[(long)ni * VV + e] = s;
+  }
+  __syncthreads();
+  const float al = alpha ? alpha[0] : 1.f;
+  if (lane < V) {
+    const int v = lane;
+    const float* p = P + (long)ni * VV;
+    float dot = 0.f;
+    for (int u = 0; u < V; ++u) dot += p[u * V + v] * D[u * V + v];
+    for (int u = 0; u < V; ++u) {
+      const int e = u * V + v;
+      dS[(long)ni * VV + e] = al * p[e] * (D[e] - dot) * inv_k;
+    }
+    dal[v] = dot;
+  }
+  if (dalpha_part) {
+    __syncthreads();
+    if (lane == 0) {
+      float s = 0.f;
+      for (int v = 0; v < V; ++v) s += dal[v];
+      dalpha_part[ni] = s;
+    }
+  }
+}
+
+// dPA[i][e] = sum_n dadj[n][i][e]  (fixed order)
+__global__ void dpa_reduce_kernel(const float* __restrict__ dadj, float* __restrict__ dPA, int N, int VV3) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= VV3) return;
+  float s = 0.f;
+  for (int n = 0; n < N; ++n) s += dadj[(long)n * VV3 + e];
+  dPA[e] = s;
+}
+
+// dtheta_i[c',t,u] = sum_v dS_i[u,v] phi_i[c',t,v];  dphi_i[c',t,v] = sum_u dS_i[u,v] theta_i[c',t,u]
+// (dS already carries the 1/K).  Also per-row sums for the conv_a/conv_b bias gradients.
+__global__ void __launch_bounds__(256)
+scores_bwd_kernel(const float* __restrict__ tp, const float* __restrict__ dS, float* __restrict__ dtp,
+                  float* __restrict__ dbpart, int N, int Ci, int T, int V, int tt, int ntiles) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int ttv = tt * V;
+  const int VS = (V + 1) >> 1, VP = 2 * VS;
+  float* Th = smem;                      // [SC_CK*tt][V]
+  float* Ph = smem + SC_CK * ttv;
+  float* B1 = Ph + SC_CK * ttv;          // [VP][32]: B1[k=v][col=u] = dS[u][v]
+  float* B2 = B1 + VP * 32;              // [VP][32]: B2[k=u][col=v] = dS[u][v]
+  float* rows = B2 + VP * 32;            // [2][SC_CK*tt] row sums
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int lr = lane & 31, h = lane >> 5;
+  const int n = blockIdx.x / ntiles, tile = blockIdx.x - n * ntiles;
+  const int i = blockIdx.y;
+  const int t0 = tile * tt;
+  const int tvalid = min(tt, T - t0);
+  const int nvalid = tvalid * V;
+  const long P = (long)T * V;
+  const long row0 = (long)n * 6 * Ci + (long)i * 2 * Ci;
+  const float* dsn = dS + ((long)n * 3 + i) * V * V;
+  for (int e = tid; e < VP * 32; e += 256) {
+    const int k = e >> 5, col = e & 31;
+    const bool ok = k < V && col < V;
+    B1[e] = ok ? dsn[col * V + k] : 0.f;
+    B2[e] = ok ? dsn[k * V + col] : 0.f;
+  }
+  const int nrows = SC_CK * tt;
+  const int nrt = (nrows + 31) >> 5;
+  for (int c0 = 0; c0 < Ci; c0 += SC_CK) {
+    __syncthreads();
+    for (int cl = wave; cl < SC_CK; cl += 4) {
+      const bool ok = (c0 + cl) < Ci;
+      const float* s1 = tp + (row0 + c0 + (ok ? cl : 0)) * P + (long)t0 * V;
+      const float* s2 = s1 + (long)Ci * P;
+      for (int q = lane; q < ttv; q += 64) {
+        const bool v = ok && q < nvalid;
+        Th[cl * ttv + q] = v ? s1[q] : 0.f;
+        Ph[cl * ttv + q] = v ? s2[q] : 0.f;
+      }
+    }
+    __syncthreads();
+    // tiles 0..nrt-1: dtheta from phi rows ; nrt..2nrt-1: dphi from theta rows
+    for (int tl = wave; tl < 2 * nrt; tl += 4) {
+      const int which = tl / nrt, rt = tl - which * nrt;
+      const float* src = which == 0 ? Ph : Th;
+      const float* Bf = which == 0 ? B1 : B2;
+      const int row = min(rt * 32 + lr, nrows - 1);
+      f32x16 d;
+#pragma unroll
+      for (int j = 0; j < 16; ++j) d[j] = 0.f;
+      for (int s = 0; s < VS; ++s) {
+        const int k = 2 * s + h;
+        float av = src[row * V + min(k, V - 1)];
+        av = (k < V) ? av : 0.f;
+        d = mfma32(av, Bf[k * 32 + lr], d);
+      }
+#pragma unroll
+      for (int j = 0; j < 16; ++j) {
+        const int r2 = rt * 32 + mfma_row(j, h);
+        const int cl = r2 / tt, t_l = r2 - cl * tt;
+        const bool ok = r2 < nrows && (c0 + cl) < Ci && t_l < tvalid;
+        const float val = (ok && lr < V) ? d[j] : 0.f;
+        if (ok && lr < V)
+          dtp[(row0 + (long)which * Ci + c0 + cl) * P + (long)(t0 + t_l) * V + lr] = val;
+        const float rs = half_sum(val);
+        if (lr == 0 && r2 < nrows) rows[which * nrows + r2] = rs;
+      }
+    }
+    __syncthreads();
+    if (dbpart) {
+      for (int e = tid; e < 2 * SC_CK; e += 256) {
+        const int which = e / SC_CK, cl = e - which * SC_CK;
+        if (c0 + cl < Ci) {
+          float s = 0.f;
+          for (int t = 0; t < tt; ++t) s += rows[which * nrows + cl * tt + t];
+          dbpart[((long)n * ntiles + tile) * 6 * Ci + (long)i * 2 * Ci + (long)which * Ci + c0 + cl] = s;
+        }
+      }
+    }
+  }
+}
+
+// out[j] = sum_slot part[slot][j]
+__global__ void slot_reduce_kernel(const float* __restrict__ part, float* __restrict__ out, int nslots, int width) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= width) return;
+  float s = 0.f;
+  for (int k = 0; k < nslots; ++k) s += part[(long)k * width + j];
+  out[j] = s;
+}
+
+inline int sc_tile_frames(int V, int T) {
+  int tt = 256 / V;
+  return tt > T ? T : tt;
+}
+
+}  // namespace
+
+extern "C" {
+
+int agcn_scores_num_tiles(int V, int T) {
+  int tt = sc_tile_frames(V, T);
+  return (T + tt - 1) / tt;
+}
+
+// spart: (N,3,ntiles,V,V) scratch ; P, adj: (N,3,V,V).  A may be null (AAGCN), alpha may be null (AGCN).
+int agcn_adjacency_fwd(const float* tp, const float* A, const float* PA, const float* alpha, float* spart, float* P,
+                       float* adj, int N, int Ci, int T, int V, void* stream) {
+  if (!tp || !PA || !spart || !P || !adj || N <= 0 || Ci <= 0 || T <= 0 || V <= 0 || V > 32) return AGCN_ERR_ARG;
+  hipStream_t s = (hipStream_t)stream;
+  const int tt = sc_tile_frames(V, T), ntiles = (T + tt - 1) / tt;
+  const size_t smem = 4 * ((size_t)2 * SC_CK * tt * V + 4 * V * V);
+  hipLaunchKernelGGL(scores_fwd_kernel, dim3(N * ntiles, 3), dim3(256), smem, s, tp, spart, N, Ci, T, V, tt, ntiles);
+  int rc = agcn_check_launch();
+  if (rc) return rc;
+  hipLaunchKernelGGL(adj_finalize_kernel, dim3(N * 3), dim3(64), 0, s, (const float*)spart, A, PA, alpha, P, adj, V,
+                     ntiles, 1.0f / ((float)Ci * (float)T));
+  return agcn_check_launch();
+}
+
+// dadj_part: (N,3,nslots,V,V) from agcn_gcn_dadj ; outputs: dadj (N,3,V,V) scratch, dS (N,3,V,V), dPA (3,V,V),
+// dalpha_part (N*3) or null
+int agcn_adjacency_bwd_softmax(const float* dadj_part, const float* P, const float* alpha, float* dadj, float* dS,
+                               float* dPA, float* dalpha_part, int N, int Ci, int T, int V, int nslots,
+                               void* stream) {
+  if (!dadj_part || !P || !dadj || !dS || !dPA || N <= 0 || V <= 0 || V > 32 || nslots <= 0) return AGCN_ERR_ARG;
+  hipStream_t s = (hipStream_t)stream;
+  hipLaunchKernelGGL(adj_bwd_kernel, dim3(N * 3), dim3(64), 0, s, dadj_part, P, alpha, dadj, dS, dalpha_part, V,
+                     nslots, 1.0f / ((float)Ci * (float)T));
+  int rc = agcn_check_launch();
+  if (rc) return rc;
+  const int VV3 = 3 * V * V;
+  hipLaunchKernelGGL(dpa_reduce_kernel, dim3((VV3 + 255) / 256), dim3(256), 0, s, (const float*)dadj, dPA, N, VV3);
+  return agcn_check_launch();
+}
+
+// dtp: (N,6Ci,T*V) ; dbpart: (N*ntiles, 6Ci) scratch ; db: (6Ci)
+int agcn_adjacency_bwd_scores(const float* tp, const float* dS, float* dtp, float* dbpart, float* db, int N, int Ci,
+                              int T, int V, void* stream) {
+  if (!tp || !dS || !dtp || !dbpart || !db || N <= 0 || Ci <= 0 || T <= 0 || V <= 0 || V > 32) return AGCN_ERR_ARG;
+  hipStream_t s = (hipStream_t)stream;
+  const int tt = sc_tile_frames(V, T), ntiles = (T + tt - 1) / tt;
+  const int VP = 2 * ((V + 1) / 2);
+  const size_t smem = 4 * ((size_t)2 * SC_CK * tt * V + 2 * VP * 32 + 2 * SC_CK * tt);
+  hipLaunchKernelGGL(scores_bwd_kernel, dim3(N * ntiles, 3), dim3(256), smem, s, tp, dS, dtp, dbpart, N, Ci, T, V, tt,
+                     ntiles);
+  int rc = agcn_check_launch();
+  if (rc) return rc;
+  const int width = 6 * Ci;
+  hipLaunchKernelGGL(slot_reduce_kernel, dim3((width + 255) / 256), dim3(256), 0, s, (const float*)dbpart, db,
+                     N * ntiles, width);
+  return agcn_check_launch();
+}
+
+}  // extern "C"

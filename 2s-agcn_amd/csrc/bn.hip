@@ -1,0 +1,269 @@
+// Train/eval BatchNorm2d + residual + ReLU passes of unit_gcn / unit_tcn / TCN_GCN_unit
+// (reference agcn.py:43,49,74,79,107-109,128-129).  HBM-bound elementwise and per-channel reduction kernels on
+// (N, C, P=T*V) fp32 tensors; channel statistics come from the partial (sum, sumsq) slabs the contraction
+// kernels emit in their epilogue and are combined here in double precision, in a fixed order.
+#include "agcn_common.h"
+
+namespace {
+
+// ---- forward statistics -> mean / invstd / folded affine, running-stat update (momentum, unbiased var) ----
+__global__ void bn_stats_finalize_kernel(const float* __restrict__ part, int nslots, int C, double count,
+                                         const float* __restrict__ gamma, const float* __restrict__ beta,
+                                         float* __restrict__ rmean, float* __restrict__ rvar, float momentum,
+                                         float eps, float* __restrict__ mean_out, float* __restrict__ invstd_out,
+                                         float* __restrict__ scale_out, float* __restrict__ shift_out) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  double s = 0.0, ss = 0.0;
+  for (int k = 0; k < nslots; ++k) {
+    s += (double)part[((long)k * 2 + 0) * C + c];
+    ss += (double)part[((long)k * 2 + 1) * C + c];
+  }
+  const double mean = s / count;
+  double var = ss / count - mean * mean;
+  if (var < 0.0) var = 0.0;
+  const float invstd = (float)(1.0 / sqrt(var + (double)eps));
+  mean_out[c] = (float)mean;
+  invstd_out[c] = invstd;
+  const float sc = gamma[c] * invstd;
+  scale_out[c] = sc;
+  shift_out[c] = beta[c] - (float)mean * sc;
+  if (rmean) {
+    const double unb = count > 1.0 ? var * count / (count - 1.0) : var;
+    rmean[c] = (1.f - momentum) * rmean[c] + momentum * (float)mean;
+    rvar[c] = (1.f - momentum) * rvar[c] + momentum * (float)unb;
+  }
+}
+
+__global__ void bn_eval_coeff_kernel(const float* __restrict__ gamma, const float* __restrict__ beta,
+                                     const float* __restrict__ rmean, const float* __restrict__ rvar, float eps, int C,
+                                     float* __restrict__ scale_out, float* __restrict__ shift_out) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  const float sc = gamma[c] / sqrtf(rvar[c] + eps);
+  scale_out[c] = sc;
+  shift_out[c] = beta[c] - rmean[c] * sc;
+}
+
+// out = act( scale1[c]*y1 + shift1[c] + res ),  res = 0 | r | scale2[c]*r + shift2[c]
+template <int RES, bool RELU>
+__global__ void __launch_bounds__(256)
+bn_act_fwd_kernel(const float4* __restrict__ y1, const float* __restrict__ scale1, const float* __restrict__ shift1,
+                  const float4* __restrict__ r, const float* __restrict__ scale2, const float* __restrict__ shift2,
+                  float4* __restrict__ out, unsigned total4, unsigned P, unsigned C) {
+  for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += gridDim.x * blockDim.x) {
+    const unsigned e0 = i * 4u;
+    const unsigned row = e0 / P;
+    const unsigned rem = e0 - row * P;
+    const unsigned c0 = row % C;
+    const unsigned c1 = (c0 + 1 == C) ? 0u : c0 + 1;
+    const float4 a = y1[i];
+    float4 b = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (RES != 0) b = r[i];
+    float av[4] = {a.x, a.y, a.z, a.w};
+    float bv[4] = {b.x, b.y, b.z, b.w};
+    float ov[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const unsigned c = (rem + k < P) ? c0 : c1;
+      float v = scale1[c] * av[k] + shift1[c];
+      if (RES == 1) v += bv[k];
+      if (RES == 2) v += scale2[c] * bv[k] + shift2[c];
+      ov[k] = RELU ? fmaxf(v, 0.f) : v;
+    }
+    out[i] = make_float4(ov[0], ov[1], ov[2], ov[3]);
+  }
+}
+
+// per (n,c) row: s0 = sum dz, s1 = sum dz*y1, s2 = sum dz*y2, dz = dout * (mask > 0)
+template <bool HAS2>
+__global__ void __launch_bounds__(256)
+bn_bwd_reduce_kernel(const float* __restrict__ dout, const float* __restrict__ mask, const float* __restrict__ y1,
+                     const float* __restrict__ y2, float* __restrict__ part, int P) {
+  __shared__ float red[3][4];
+  const long row = blockIdx.x;
+  const float* d = dout + row * P;
+  const float* mk = mask ? mask + row * P : nullptr;
+  const float* a = y1 + row * P;
+  const float* b = HAS2 ? y2 + row * P : nullptr;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f;
+  for (int q = threadIdx.x; q < P; q += 256) {
+    float dz = d[q];
+    if (mk) dz = (mk[q] > 0.f) ? dz : 0.f;
+    s0 += dz;
+    s1 += dz * a[q];
+    if (HAS2) s2 += dz * b[q];
+  }
+  s0 = half_sum(s0); s1 = half_sum(s1); s2 = half_sum(s2);
+  s0 += __shfl_xor(s0, 32); s1 += __shfl_xor(s1, 32); s2 += __shfl_xor(s2, 32);
+  const int wave = threadIdx.x >> 6;
+  if ((threadIdx.x & 63) == 0) { red[0][wave] = s0; red[1][wave] = s1; red[2][wave] = s2; }
+  __syncthreads();
+  if (threadIdx.x < 3) {
+    const int k = threadIdx.x;
+    part[row * 3 + k] = red[k][0] + red[k][1] + red[k][2] + red[k][3];
+  }
+}
+
+// coef[0..2][C] = (A1,B1,C1) with dy1 = A1*dz + B1*y1 + C1 ; coef[3..5][C] same for branch 2
+__global__ void bn_bwd_finalize_kernel(const float* __restrict__ part, int N, int C, double count,
+                                       const float* __restrict__ gamma1, const float* __restrict__ mean1,
+                                       const float* __restrict__ invstd1, const float* __restrict__ gamma2,
+                                       const float* __restrict__ mean2, const float* __restrict__ invstd2,
+                                       float* __restrict__ coef, float* __restrict__ dgamma1,
+                                       float* __restrict__ dbeta1, float* __restrict__ dgamma2,
+                                       float* __restrict__ dbeta2) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  double s0 = 0.0, s1 = 0.0, s2 = 0.0;
+  for (int n = 0; n < N; ++n) {
+    const float* p = part + ((long)n * C + c) * 3;
+    s0 += (double)p[0]; s1 += (double)p[1]; s2 += (double)p[2];
+  }
+  {
+    const double is = invstd1[c], mu = mean1[c], g = gamma1[c];
+    const double sxh = is * (s1 - mu * s0);     // sum dz * xhat
+    const double k = g * is;
+    coef[0 * C + c] = (float)k;
+    coef[1 * C + c] = (float)(-k * is * sxh / count);
+    coef[2 * C + c] = (float)(-k * s0 / count + k * is * mu * sxh / count);
+    dgamma1[c] = (float)sxh;
+    dbeta1[c] = (float)s0;
+  }
+  if (gamma2) {
+    const double is = invstd2[c], mu = mean2[c], g = gamma2[c];
+    const double sxh = is * (s2 - mu * s0);
+    const double k = g * is;
+    coef[3 * C + c] = (float)k;
+    coef[4 * C + c] = (float)(-k * is * sxh / count);
+    coef[5 * C + c] = (float)(-k * s0 / count + k * is * mu * sxh / count);
+    dgamma2[c] = (float)sxh;
+    dbeta2[c] = (float)s0;
+  }
+}
+
+template <bool HAS2>
+__global__ void __launch_bounds__(256)
+bn_bwd_apply_kernel(const float4* __restrict__ dout, const float4* __restrict__ mask, const float4* __restrict__ y1,
+                    const float4* __restrict__ y2, const float* __restrict__ coef, float4* __restrict__ dy1,
+                    float4* __restrict__ dy2, unsigned total4, unsigned P, unsigned C) {
+  for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += gridDim.x * blockDim.x) {
+    const unsigned e0 = i * 4u;
+    const unsigned row = e0 / P;
+    const unsigned rem = e0 - row * P;
+    const unsigned c0 = row % C;
+    const unsigned c1 = (c0 + 1 == C) ? 0u : c0 + 1;
+    const float4 d4 = dout[i];
+    const float4 a4 = y1[i];
+    float dv[4] = {d4.x, d4.y, d4.z, d4.w};
+    float av[4] = {a4.x, a4.y, a4.z, a4.w};
+    if (mask) {
+      const float4 m4 = mask[i];
+      const float mv[4] = {m4.x, m4.y, m4.z, m4.w};
+#pragma unroll
+      for (int k = 0; k < 4; ++k) dv[k] = (mv[k] > 0.f) ? dv[k] : 0.f;
+    }
+    float bv[4] = {0.f, 0.f, 0.f, 0.f};
+    if (HAS2) {
+      const float4 b4 = y2[i];
+      bv[0] = b4.x; bv[1] = b4.y; bv[2] = b4.z; bv[3] = b4.w;
+    }
+    float o1[4], o2[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const unsigned c = (rem + k < P) ? c0 : c1;
+      o1[k] = coef[0 * C + c] * dv[k] + coef[1 * C + c] * av[k] + coef[2 * C + c];
+      if (HAS2) o2[k] = coef[3 * C + c] * dv[k] + coef[4 * C + c] * bv[k] + coef[5 * C + c];
+    }
+    dy1[i] = make_float4(o1[0], o1[1], o1[2], o1[3]);
+    if (HAS2) dy2[i] = make_float4(o2[0], o2[1], o2[2], o2[3]);
+  }
+}
+
+inline unsigned ew_grid(unsigned total4) {
+  unsigned g = (total4 + 255u) / 256u;
+  return g > 4096u ? 4096u : (g ? g : 1u);
+}
+
+}  // namespace
+
+extern "C" {
+
+// part: [nslots][2][C] from the contraction epilogue ; count = N*T*V ; rmean/rvar may be null (no update)
+int agcn_bn_stats_finalize(const float* part, int nslots, int C, double count, const float* gamma, const float* beta,
+                           float* running_mean, float* running_var, float momentum, float eps, float* mean,
+                           float* invstd, float* scale, float* shift, void* stream) {
+  if (!part || !gamma || !beta || !mean || !invstd || !scale || !shift || C <= 0 || nslots <= 0) return AGCN_ERR_ARG;
+  hipLaunchKernelGGL(bn_stats_finalize_kernel, dim3((C + 63) / 64), dim3(64), 0, (hipStream_t)stream, part, nslots, C,
+                     count, gamma, beta, running_mean, running_var, momentum, eps, mean, invstd, scale, shift);
+  return agcn_check_launch();
+}
+
+int agcn_bn_eval_coeff(const float* gamma, const float* beta, const float* running_mean, const float* running_var,
+                       float eps, int C, float* scale, float* shift, void* stream) {
+  if (!gamma || !beta || !running_mean || !running_var || !scale || !shift || C <= 0) return AGCN_ERR_ARG;
+  hipLaunchKernelGGL(bn_eval_coeff_kernel, dim3((C + 63) / 64), dim3(64), 0, (hipStream_t)stream, gamma, beta,
+                     running_mean, running_var, eps, C, scale, shift);
+  return agcn_check_launch();
+}
+
+// res_mode: 0 none, 1 identity residual r, 2 BN'd residual branch scale2*r+shift2 ; total = N*C*P must be %4
+int agcn_bn_act_fwd(const float* y1, const float* scale1, const float* shift1, const float* r, const float* scale2,
+                    const float* shift2, float* out, int N, int C, int P, int res_mode, int relu, void* stream) {
+  if (!y1 || !scale1 || !shift1 || !out || N <= 0 || C <= 0 || P <= 0) return AGCN_ERR_ARG;
+  const long total = (long)N * C * P;
+  if (total % 4 != 0 || total / 4 > 0x7fffffffL) return AGCN_ERR_UNSUPPORTED;
+  if (res_mode != 0 && !r) return AGCN_ERR_ARG;
+  if (res_mode == 2 && (!scale2 || !shift2)) return AGCN_ERR_ARG;
+  const unsigned t4 = (unsigned)(total / 4);
+  hipStream_t s = (hipStream_t)stream;
+  const dim3 g(ew_grid(t4)), b(256);
+#define LAUNCH_ACT(R, A)                                                                                       \
+  hipLaunchKernelGGL((bn_act_fwd_kernel<R, A>), g, b, 0, s, (const float4*)y1, scale1, shift1, (const float4*)r, \
+                     scale2, shift2, (float4*)out, t4, (unsigned)P, (unsigned)C)
+  if (relu) {
+    if (res_mode == 0) LAUNCH_ACT(0, true); else if (res_mode == 1) LAUNCH_ACT(1, true); else LAUNCH_ACT(2, true);
+  } else {
+    if (res_mode == 0) LAUNCH_ACT(0, false); else if (res_mode == 1) LAUNCH_ACT(1, false); else LAUNCH_ACT(2, false);
+  }
+#undef LAUNCH_ACT
+  return agcn_check_launch();
+}
+
+// Backward of out = relu(bn1(y1) + [bn2(y2)] + ...): dz = dout*(mask>0) (mask may be null);
+// dy1 = A1*dz + B1*y1 + C1 (train-mode BN backward), same for branch 2.  part: (N*C*3) scratch, coef: (6*C) scratch.
+int agcn_bn_bwd(const float* dout, const float* mask, const float* y1, const float* gamma1, const float* mean1,
+                const float* invstd1, const float* y2, const float* gamma2, const float* mean2, const float* invstd2,
+                float* part, float* coef, float* dy1, float* dgamma1, float* dbeta1, float* dy2, float* dgamma2,
+                float* dbeta2, int N, int C, int P, void* stream) {
+  if (!dout || !y1 || !gamma1 || !mean1 || !invstd1 || !part || !coef || !dy1 || !dgamma1 || !dbeta1) return AGCN_ERR_ARG;
+  if (y2 && (!gamma2 || !mean2 || !invstd2 || !dy2 || !dgamma2 || !dbeta2)) return AGCN_ERR_ARG;
+  const long total = (long)N * C * P;
+  if (total % 4 != 0 || total / 4 > 0x7fffffffL) return AGCN_ERR_UNSUPPORTED;
+  hipStream_t s = (hipStream_t)stream;
+  if (y2) hipLaunchKernelGGL(bn_bwd_reduce_kernel<true>, dim3(N * C), dim3(256), 0, s, dout, mask, y1, y2, part, P);
+  else hipLaunchKernelGGL(bn_bwd_reduce_kernel<false>, dim3(N * C), dim3(256), 0, s, dout, mask, y1, y2, part, P);
+  int rc = agcn_check_launch();
+  if (rc) return rc;
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 63) / 64), dim3(64), 0, s, (const float*)part, N, C,
+                     (double)N * (double)P, gamma1, mean1, invstd1, y2 ? gamma2 : nullptr, mean2, invstd2, coef,
+                     dgamma1, dbeta1, dgamma2, dbeta2);
+  rc = agcn_check_launch();
+  if (rc) return rc;
+  const unsigned t4 = (unsigned)(total / 4);
+  const dim3 g(ew_grid(t4)), b(256);
+  if (y2)
+    hipLaunchKernelGGL(bn_bwd_apply_kernel<true>, g, b, 0, s, (const float4*)dout, (const float4*)mask,
+                       (const float4*)y1, (const float4*)y2, (const float*)coef, (float4*)dy1, (float4*)dy2, t4,
+                       (unsigned)P, (unsigned)C);
+  else
+    hipLaunchKernelGGL(bn_bwd_apply_kernel<false>, g, b, 0, s, (const float4*)dout, (const float4*)mask,
+                       (const float4*)y1, (const float4*)y2, (const float*)coef, (float4*)dy1, (float4*)dy2, t4,
+                       (unsigned)P, (unsigned)C);
+  return agcn_check_launch();
+}
+
+const char* agcn_arch(void) { return "gfx950"; }
+int agcn_version(void) { return 100; }
+
+}  // extern "C"

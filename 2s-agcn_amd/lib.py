@@ -1,0 +1,86 @@
+"""ctypes binding of the C-ABI shared library ``libagcn_hip.so`` (declared in ``include/agcn_hip.h``).
+
+The library is built in-tree by ``__graft_entry__.build()`` (``hipcc --offload-arch=gfx950``).  There is NO
+fallback: if the library is missing or a call fails, a ``RuntimeError`` is raised (the product path never
+routes through the CPU oracle or stock PyTorch operators for the hot path).
+"""
+import ctypes
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libagcn_hip.so")
+
+_P = ctypes.c_void_p
+_I = ctypes.c_int
+_F = ctypes.c_float
+_D = ctypes.c_double
+_Z = ctypes.c_size_t
+
+# name -> (restype, argtypes); mirrors include/agcn_hip.h one to one
+SIGNATURES = {
+    "agcn_version": (_I, []),
+    "agcn_arch": (ctypes.c_char_p, []),
+    "agcn_conv_tile_frames": (_I, [_I, _I]),
+    "agcn_conv_num_tiles": (_I, [_I, _I]),
+    "agcn_dadj_num_slots": (_I, [_I, _I, _I]),
+    "agcn_scores_num_tiles": (_I, [_I, _I]),
+    "agcn_conv_fwd": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
+    "agcn_conv_bwd_data": (_I, [_P, _P, _P, _I, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
+    "agcn_conv_bwd_weight_workspace": (_Z, [_I, _I, _I, _I, _I, _I, _I]),
+    "agcn_conv_bwd_weight": (_I, [_P, _P, _P, _P, _Z, _I, _I, _I, _I, _I, _I, _I, _P]),
+    "agcn_gcn_aggregate_project_fwd": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
+    "agcn_gcn_aggregate_project_bwd_data": (_I, [_P, _P, _P, _P, _I, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
+    "agcn_gcn_dadj": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
+    "agcn_gcn_project_bwd_weight_workspace": (_Z, [_I, _I, _I, _I, _I]),
+    "agcn_gcn_project_bwd_weight": (_I, [_P, _P, _P, _P, _P, _Z, _I, _I, _I, _I, _I, _P]),
+    "agcn_adjacency_fwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
+    "agcn_adjacency_bwd_softmax": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
+    "agcn_adjacency_bwd_scores": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
+    "agcn_bn_stats_finalize": (_I, [_P, _I, _I, _D, _P, _P, _P, _P, _F, _F, _P, _P, _P, _P, _P]),
+    "agcn_bn_eval_coeff": (_I, [_P, _P, _P, _P, _F, _I, _P, _P, _P]),
+    "agcn_bn_act_fwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
+    "agcn_bn_bwd": (_I, [_P] * 18 + [_I, _I, _I, _P]),
+    "agcn_sgd_step_workspace": (_Z, [ctypes.c_long]),
+    "agcn_sgd_step": (_I, [_P, _P, _P, ctypes.c_long, _F, _F, _F, _I, _F, _F, _I, _P, _Z, _P, _P]),
+}
+
+_lib = None
+
+
+def load():
+    """Load the shared library (once).  Raises RuntimeError if it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"agcn_amd: HIP extension {LIB_PATH} not found -- run `python -c 'import __graft_entry__ as g; "
+            f"g.build()'` (hipcc --offload-arch=gfx950).  There is no CPU fallback for the hot path.")
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)      # AttributeError here = header/library mismatch
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def ptr(t):
+    """Device pointer of a tensor (None -> NULL).  The tensor must be contiguous fp32 on a GPU."""
+    if t is None:
+        return None
+    if not (t.is_cuda and t.is_contiguous() and t.dtype == torch.float32):
+        raise RuntimeError(f"agcn_amd: expected a contiguous fp32 GPU tensor, got {t.dtype} "
+                           f"{tuple(t.shape)} on {t.device} contiguous={t.is_contiguous()}")
+    return t.data_ptr()
+
+
+def stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def check(rc, what):
+    if rc != 0:
+        raise RuntimeError(f"agcn_amd: {what} failed with code {rc}")

@@ -1,0 +1,398 @@
+"""Host-side operators of the AGCN hot path: thin wrappers over the C-ABI (``lib.py``) and the
+``torch.autograd.Function``s that chain them into unit_gcn / unit_tcn / TCN_GCN_unit forward+backward.
+
+Tensors are (N', C, T, V) contiguous fp32 on the GPU, allocated by PyTorch's caching allocator; the
+extension never allocates or keeps device memory.  Everything here launches on the current stream.
+
+Maths: SURVEY.md Appendix A (checked against the reference ``agcn.py:92-109`` by the oracle tests).
+"""
+import torch
+
+from . import lib as _lib
+
+BN_EPS = 1e-5
+BN_MOMENTUM = 0.1
+
+
+def _L():
+    return _lib.load()
+
+
+def _empty(shape, like):
+    return torch.empty(shape, dtype=torch.float32, device=like.device)
+
+
+# ------------------------------------------------------------------------------------------------
+# thin wrappers (one C entry point each)
+# ------------------------------------------------------------------------------------------------
+
+def conv_out_frames(T, taps, stride):
+    pad = (taps - 1) // 2
+    return (T + 2 * pad - taps) // stride + 1
+
+
+def conv_fwd(x, w, b, stride=1, want_stats=False):
+    """y = conv2d(x, w(k,1), b, stride=(s,1), padding=((k-1)/2,0)); optional per-channel (sum,sumsq) partials."""
+    N, Cin, T, V = x.shape
+    Cout, Cin2, taps, one = w.shape
+    assert Cin2 == Cin and one == 1
+    To = conv_out_frames(T, taps, stride)
+    y = _empty((N, Cout, To, V), x)
+    stats = None
+    if want_stats:
+        nt = _L().agcn_conv_num_tiles(V, To)
+        stats = _empty((N * nt, 2, Cout), x)
+    _lib.check(_L().agcn_conv_fwd(_lib.ptr(x), _lib.ptr(w), _lib.ptr(b), _lib.ptr(y), _lib.ptr(stats),
+                                  N, Cin, Cout, T, V, taps, stride, _lib.stream()), "agcn_conv_fwd")
+    return y, stats
+
+
+def conv_bwd_data(dy, w, x_shape, stride=1, out=None, accumulate=False, add1=None, mask1=None, add2=None,
+                  mask2=None):
+    N, Cin, T, V = x_shape
+    Cout, _, taps, _ = w.shape
+    dx = out if out is not None else _empty(x_shape, dy)
+    _lib.check(_L().agcn_conv_bwd_data(_lib.ptr(dy), _lib.ptr(w), _lib.ptr(dx), int(accumulate), _lib.ptr(add1),
+                                       _lib.ptr(mask1), _lib.ptr(add2), _lib.ptr(mask2), N, Cin, Cout, T, V, taps,
+                                       stride, _lib.stream()), "agcn_conv_bwd_data")
+    return dx
+
+
+def conv_bwd_weight(dy, x, w_shape, stride=1):
+    N, Cin, T, V = x.shape
+    Cout, _, taps, _ = w_shape
+    nbytes = _L().agcn_conv_bwd_weight_workspace(N, Cin, Cout, T, V, taps, stride)
+    ws = torch.empty((nbytes + 3) // 4, dtype=torch.float32, device=x.device)
+    dw = _empty(tuple(w_shape), x)
+    _lib.check(_L().agcn_conv_bwd_weight(_lib.ptr(dy), _lib.ptr(x), _lib.ptr(dw), _lib.ptr(ws), nbytes, N, Cin, Cout,
+                                         T, V, taps, stride, _lib.stream()), "agcn_conv_bwd_weight")
+    return dw
+
+
+def adjacency_fwd(tp, A, PA, alpha=None):
+    """tp: (N, 6Ci, T, V) theta/phi; returns P (softmax) and adj = [alpha*]P + A + PA, both (N,3,V,V)."""
+    N, C6, T, V = tp.shape
+    Ci = C6 // 6
+    nt = _L().agcn_scores_num_tiles(V, T)
+    spart = _empty((N, 3, nt, V, V), tp)
+    P = _empty((N, 3, V, V), tp)
+    adj = _empty((N, 3, V, V), tp)
+    _lib.check(_L().agcn_adjacency_fwd(_lib.ptr(tp), _lib.ptr(A), _lib.ptr(PA), _lib.ptr(alpha), _lib.ptr(spart),
+                                       _lib.ptr(P), _lib.ptr(adj), N, Ci, T, V, _lib.stream()), "agcn_adjacency_fwd")
+    return P, adj
+
+
+def aggregate_project_fwd(x, adj, wcat, bias, want_stats=False):
+    """y = sum_i Wd_i (x . adj_i) + bias ; wcat: (Cout, 3C) = [Wd_0 | Wd_1 | Wd_2]."""
+    N, C, T, V = x.shape
+    Cout = wcat.shape[0]
+    y = _empty((N, Cout, T, V), x)
+    stats = None
+    if want_stats:
+        nt = _L().agcn_conv_num_tiles(V, T)
+        stats = _empty((N * nt, 2, Cout), x)
+    _lib.check(_L().agcn_gcn_aggregate_project_fwd(_lib.ptr(x), _lib.ptr(adj), _lib.ptr(wcat), _lib.ptr(bias),
+                                                   _lib.ptr(y), _lib.ptr(stats), N, C, Cout, T, V, _lib.stream()),
+               "agcn_gcn_aggregate_project_fwd")
+    return y, stats
+
+
+def aggregate_project_bwd_data(dy, adj, wcat, x_shape, out=None, accumulate=False, add1=None, mask1=None,
+                               add2=None, mask2=None):
+    N, C, T, V = x_shape
+    Cout = wcat.shape[0]
+    dx = out if out is not None else _empty(x_shape, dy)
+    _lib.check(_L().agcn_gcn_aggregate_project_bwd_data(
+        _lib.ptr(dy), _lib.ptr(adj), _lib.ptr(wcat), _lib.ptr(dx), int(accumulate), _lib.ptr(add1), _lib.ptr(mask1),
+        _lib.ptr(add2), _lib.ptr(mask2), N, C, Cout, T, V, _lib.stream()), "agcn_gcn_aggregate_project_bwd_data")
+    return dx
+
+
+def project_bwd_weight(dy, x, adj, Cout):
+    N, C, T, V = x.shape
+    nbytes = _L().agcn_gcn_project_bwd_weight_workspace(N, C, Cout, T, V)
+    ws = torch.empty((nbytes + 3) // 4, dtype=torch.float32, device=x.device)
+    dw = _empty((Cout, 3 * C), x)
+    _lib.check(_L().agcn_gcn_project_bwd_weight(_lib.ptr(dy), _lib.ptr(x), _lib.ptr(adj), _lib.ptr(dw), _lib.ptr(ws),
+                                                nbytes, N, C, Cout, T, V, _lib.stream()),
+               "agcn_gcn_project_bwd_weight")
+    return dw
+
+
+def adjacency_bwd(dy, wcat, x, tp, P, alpha=None):
+    """Gradient of the adaptive adjacency branch.  Returns dPA (3,V,V), dtp (N,6Ci,T,V), dbab (6Ci), dalpha."""
+    N, C, T, V = x.shape
+    Cout = wcat.shape[0]
+    Ci = tp.shape[1] // 6
+    nslots = _L().agcn_dadj_num_slots(C, V, T)
+    dpart = _empty((N, 3, nslots, V, V), x)
+    _lib.check(_L().agcn_gcn_dadj(_lib.ptr(dy), _lib.ptr(wcat), _lib.ptr(x), _lib.ptr(dpart), N, C, Cout, T, V,
+                                  _lib.stream()), "agcn_gcn_dadj")
+    dadj = _empty((N, 3, V, V), x)
+    dS = _empty((N, 3, V, V), x)
+    dPA = _empty((3, V, V), x)
+    dal_part = _empty((N * 3,), x) if alpha is not None else None
+    _lib.check(_L().agcn_adjacency_bwd_softmax(_lib.ptr(dpart), _lib.ptr(P), _lib.ptr(alpha), _lib.ptr(dadj),
+                                               _lib.ptr(dS), _lib.ptr(dPA), _lib.ptr(dal_part), N, Ci, T, V, nslots,
+                                               _lib.stream()), "agcn_adjacency_bwd_softmax")
+    nt = _L().agcn_scores_num_tiles(V, T)
+    dtp = _empty(tuple(tp.shape), x)
+    dbpart = _empty((N * nt, 6 * Ci), x)
+    dbab = _empty((6 * Ci,), x)
+    _lib.check(_L().agcn_adjacency_bwd_scores(_lib.ptr(tp), _lib.ptr(dS), _lib.ptr(dtp), _lib.ptr(dbpart),
+                                              _lib.ptr(dbab), N, Ci, T, V, _lib.stream()),
+               "agcn_adjacency_bwd_scores")
+    dalpha = dal_part.sum() if dal_part is not None else None
+    return dPA, dtp, dbab, dalpha, dadj
+
+
+class BNState:
+    """Per-BatchNorm forward products kept for the backward."""
+    __slots__ = ("mean", "invstd", "scale", "shift")
+
+
+def bn_train_coeffs(stats_part, count, gamma, beta, running_mean, running_var, momentum=BN_MOMENTUM, eps=BN_EPS):
+    C = gamma.numel()
+    st = BNState()
+    st.mean, st.invstd = _empty((C,), gamma), _empty((C,), gamma)
+    st.scale, st.shift = _empty((C,), gamma), _empty((C,), gamma)
+    nslots = stats_part.shape[0]
+    _lib.check(_L().agcn_bn_stats_finalize(_lib.ptr(stats_part), nslots, C, float(count), _lib.ptr(gamma),
+                                           _lib.ptr(beta), _lib.ptr(running_mean), _lib.ptr(running_var),
+                                           float(momentum), float(eps), _lib.ptr(st.mean), _lib.ptr(st.invstd),
+                                           _lib.ptr(st.scale), _lib.ptr(st.shift), _lib.stream()),
+               "agcn_bn_stats_finalize")
+    return st
+
+
+def bn_eval_coeffs(gamma, beta, running_mean, running_var, eps=BN_EPS):
+    C = gamma.numel()
+    st = BNState()
+    st.mean = st.invstd = None
+    st.scale, st.shift = _empty((C,), gamma), _empty((C,), gamma)
+    _lib.check(_L().agcn_bn_eval_coeff(_lib.ptr(gamma), _lib.ptr(beta), _lib.ptr(running_mean),
+                                       _lib.ptr(running_var), float(eps), C, _lib.ptr(st.scale), _lib.ptr(st.shift),
+                                       _lib.stream()), "agcn_bn_eval_coeff")
+    return st
+
+
+def bn_act_fwd(y1, st1, r=None, st2=None, relu=True):
+    """out = act(scale1*y1 + shift1 + res); res = 0 (r None) | r (st2 None) | scale2*r + shift2."""
+    N, C, T, V = y1.shape
+    out = torch.empty_like(y1)
+    mode = 0 if r is None else (1 if st2 is None else 2)
+    _lib.check(_L().agcn_bn_act_fwd(_lib.ptr(y1), _lib.ptr(st1.scale), _lib.ptr(st1.shift), _lib.ptr(r),
+                                    _lib.ptr(st2.scale) if st2 else None, _lib.ptr(st2.shift) if st2 else None,
+                                    _lib.ptr(out), N, C, T * V, mode, int(relu), _lib.stream()), "agcn_bn_act_fwd")
+    return out
+
+
+def bn_bwd(dout, mask, y1, gamma1, st1, y2=None, gamma2=None, st2=None):
+    """Backward through out = relu(bn1(y1) [+ bn2(y2)] [+ identity]) in train mode.
+    Returns dy1, dgamma1, dbeta1, dy2, dgamma2, dbeta2 (branch-2 entries None without y2)."""
+    N, C, T, V = y1.shape
+    part = _empty((N * C * 3,), y1)
+    coef = _empty((6 * C,), y1)
+    dy1 = torch.empty_like(y1)
+    dg1, db1 = _empty((C,), y1), _empty((C,), y1)
+    dy2 = dg2 = db2 = None
+    if y2 is not None:
+        dy2 = torch.empty_like(y2)
+        dg2, db2 = _empty((C,), y1), _empty((C,), y1)
+    _lib.check(_L().agcn_bn_bwd(
+        _lib.ptr(dout), _lib.ptr(mask), _lib.ptr(y1), _lib.ptr(gamma1), _lib.ptr(st1.mean), _lib.ptr(st1.invstd),
+        _lib.ptr(y2), _lib.ptr(gamma2), _lib.ptr(st2.mean) if st2 else None, _lib.ptr(st2.invstd) if st2 else None,
+        _lib.ptr(part), _lib.ptr(coef), _lib.ptr(dy1), _lib.ptr(dg1), _lib.ptr(db1), _lib.ptr(dy2), _lib.ptr(dg2),
+        _lib.ptr(db2), N, C, T * V, _lib.stream()), "agcn_bn_bwd")
+    return dy1, dg1, db1, dy2, dg2, db2
+
+
+# ------------------------------------------------------------------------------------------------
+# unit_gcn / unit_tcn forward and backward as plain functions over a context object
+# ------------------------------------------------------------------------------------------------
+
+class _Ctx:
+    pass
+
+
+def _bn_coeffs(training, stats, count, w, b, rm, rv):
+    if training:
+        return bn_train_coeffs(stats, count, w, b, rm, rv)
+    return bn_eval_coeffs(w, b, rm, rv)
+
+
+def gcn_forward(c, x, A, PA, wab, bab, wd, bd, bn, down, training):
+    """unit_gcn.forward (reference agcn.py:92-109).
+    wab: (6Ci, C, 1, 1) rows [a0|b0|a1|b1|a2|b2]; wd: (Cout, 3C); bd: summed conv_d biases;
+    bn = (weight, bias, running_mean, running_var); down = None | (w, b, bn_w, bn_b, bn_rm, bn_rv)."""
+    N, C, T, V = x.shape
+    count = N * T * V
+    tp, _ = conv_fwd(x, wab, bab)
+    P, adj = adjacency_fwd(tp, A, PA)
+    ypre, st = aggregate_project_fwd(x, adj, wd, bd, want_stats=training)
+    bn1 = _bn_coeffs(training, st, count, *bn)
+    dpre = bn2 = None
+    if down is not None:
+        dpre, st2 = conv_fwd(x, down[0], down[1], want_stats=training)
+        bn2 = _bn_coeffs(training, st2, count, *down[2:])
+        out = bn_act_fwd(ypre, bn1, dpre, bn2, relu=True)
+    else:
+        out = bn_act_fwd(ypre, bn1, x, None, relu=True)
+    c.g_x, c.g_tp, c.g_P, c.g_adj, c.g_ypre, c.g_dpre, c.g_out = x, tp, P, adj, ypre, dpre, out
+    c.g_bn1, c.g_bn2 = bn1, bn2
+    c.g_params = (wab, wd, bn[0], down[0] if down is not None else None, down[2] if down is not None else None)
+    return out
+
+
+def gcn_backward(c, dout, extra_add=None, extra_mask=None):
+    """Backward of gcn_forward.  ``extra_add`` (masked by ``extra_mask``) is an additional dx contribution folded
+    into the epilogue of the first dx kernel (the TCN_GCN_unit identity residual)."""
+    x, tp, P, adj, ypre, dpre, out = c.g_x, c.g_tp, c.g_P, c.g_adj, c.g_ypre, c.g_dpre, c.g_out
+    wab, wd, gamma1, wdown, gamma2 = c.g_params
+    Cout = wd.shape[0]
+    dypre, dg1, db1, ddpre, dg2, db2 = bn_bwd(dout, out, ypre, gamma1, c.g_bn1, dpre, gamma2, c.g_bn2)
+    dwd = project_bwd_weight(dypre, x, adj, Cout)
+    if dpre is None:      # identity `down`: dx += dout * (out > 0)
+        dx = aggregate_project_bwd_data(dypre, adj, wd, x.shape, add1=dout, mask1=out, add2=extra_add,
+                                        mask2=extra_mask)
+    else:
+        dx = aggregate_project_bwd_data(dypre, adj, wd, x.shape, add1=extra_add, mask1=extra_mask)
+    dPA, dtp, dbab, _, _ = adjacency_bwd(dypre, wd, x, tp, P)
+    dwab = conv_bwd_weight(dtp, x, wab.shape)
+    conv_bwd_data(dtp, wab, x.shape, out=dx, accumulate=True)
+    dwdown = None
+    if dpre is not None:
+        dwdown = conv_bwd_weight(ddpre, x, wdown.shape)
+        conv_bwd_data(ddpre, wdown, x.shape, out=dx, accumulate=True)
+    return dx, dPA, dwab, dbab, dwd, dg1, db1, dwdown, dg2, db2
+
+
+def tcn_forward(c, g, w, b, bn, stride, res_x, res, relu, training):
+    """unit_tcn.forward (reference agcn.py:48-50) optionally fused with the TCN_GCN_unit tail
+    relu(tcn(g) + residual(x)) (agcn.py:127-129).  res = None (no residual) | 'identity' |
+    (w, b, bn_w, bn_b, bn_rm, bn_rv) for the unit_tcn(kernel_size=1, stride) residual."""
+    N, C, T, V = g.shape
+    zpre, st = conv_fwd(g, w, b, stride, want_stats=training)
+    To = zpre.shape[2]
+    count = N * To * V
+    bn1 = _bn_coeffs(training, st, count, *bn)
+    rpre = bn2 = None
+    if res is None:
+        out = bn_act_fwd(zpre, bn1, None, None, relu=relu)
+    elif isinstance(res, str):
+        out = bn_act_fwd(zpre, bn1, res_x, None, relu=relu)
+    else:
+        rpre, st2 = conv_fwd(res_x, res[0], res[1], stride, want_stats=training)
+        bn2 = _bn_coeffs(training, st2, count, *res[2:])
+        out = bn_act_fwd(zpre, bn1, rpre, bn2, relu=relu)
+    c.t_g, c.t_zpre, c.t_rpre, c.t_out, c.t_bn1, c.t_bn2 = g, zpre, rpre, out, bn1, bn2
+    c.t_resx, c.t_res_identity = res_x, isinstance(res, str)
+    c.t_params = (w, bn[0], res[0] if isinstance(res, tuple) else None, res[2] if isinstance(res, tuple) else None)
+    c.t_stride, c.t_relu = stride, relu
+    return out
+
+
+def tcn_backward(c, dout):
+    """Returns dg, dw, dgamma, dbeta, (drpre, dw_res, dgamma_res, dbeta_res)."""
+    w, gamma1, wres, gamma2 = c.t_params
+    mask = c.t_out if c.t_relu else None
+    dzpre, dg1, db1, drpre, dg2, db2 = bn_bwd(dout, mask, c.t_zpre, gamma1, c.t_bn1, c.t_rpre, gamma2, c.t_bn2)
+    dw = conv_bwd_weight(dzpre, c.t_g, w.shape, c.t_stride)
+    dg = conv_bwd_data(dzpre, w, c.t_g.shape, c.t_stride)
+    dwres = None
+    if drpre is not None:
+        dwres = conv_bwd_weight(drpre, c.t_resx, wres.shape, c.t_stride)
+    return dg, dw, dg1, db1, drpre, dwres, dg2, db2
+
+
+def _need_train(training):
+    if not training:
+        raise NotImplementedError("agcn_amd: backward through eval-mode BatchNorm is not implemented; call "
+                                  "model.train() for training or torch.no_grad() for inference")
+
+
+class UnitGCNFunction(torch.autograd.Function):
+    """unit_gcn: args (x, A, PA, wab, bab, wd, bd, bn_w, bn_b, bn_rm, bn_rv,
+                       down_w, down_b, dbn_w, dbn_b, dbn_rm, dbn_rv, training)"""
+
+    @staticmethod
+    def forward(ctx, x, A, PA, wab, bab, wd, bd, bn_w, bn_b, bn_rm, bn_rv, down_w, down_b, dbn_w, dbn_b, dbn_rm,
+                dbn_rv, training):
+        c = _Ctx()
+        down = None if down_w is None else (down_w, down_b, dbn_w, dbn_b, dbn_rm, dbn_rv)
+        out = gcn_forward(c, x.contiguous(), A, PA, wab, bab, wd, bd, (bn_w, bn_b, bn_rm, bn_rv), down, training)
+        ctx.c, ctx.training = c, training
+        ctx.has_down = down is not None
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        _need_train(ctx.training)
+        dx, dPA, dwab, dbab, dwd, dg1, db1, dwdown, dg2, db2 = gcn_backward(ctx.c, dout.contiguous())
+        zb = lambda t: torch.zeros(t.shape[0], dtype=torch.float32, device=dout.device)  # noqa: E731
+        dbd = zb(dwd)
+        dbdown = zb(dwdown) if ctx.has_down else None
+        ctx.c = None
+        return (dx, None, dPA, dwab, dbab, dwd, dbd, dg1, db1, None, None, dwdown, dbdown, dg2, db2, None, None, None)
+
+
+class UnitTCNFunction(torch.autograd.Function):
+    """unit_tcn (no residual, no ReLU): args (x, w, b, bn_w, bn_b, bn_rm, bn_rv, stride, training)"""
+
+    @staticmethod
+    def forward(ctx, x, w, b, bn_w, bn_b, bn_rm, bn_rv, stride, training):
+        c = _Ctx()
+        out = tcn_forward(c, x.contiguous(), w, b, (bn_w, bn_b, bn_rm, bn_rv), stride, None, None, False, training)
+        ctx.c, ctx.training = c, training
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        _need_train(ctx.training)
+        dg, dw, dg1, db1, _, _, _, _ = tcn_backward(ctx.c, dout.contiguous())
+        dbias = torch.zeros(dw.shape[0], dtype=torch.float32, device=dout.device)
+        ctx.c = None
+        return dg, dw, dbias, dg1, db1, None, None, None, None
+
+
+class TCNGCNUnitFunction(torch.autograd.Function):
+    """TCN_GCN_unit = relu(tcn1(gcn1(x)) + residual(x)) as ONE autograd node, so that every dx contribution is
+    accumulated in a contraction epilogue instead of separate elementwise passes.
+
+    args: x, A, PA, wab, bab, wd, bd, gbn_w, gbn_b, gbn_rm, gbn_rv, down_w, down_b, dbn_w, dbn_b, dbn_rm, dbn_rv,
+          tw, tb, tbn_w, tbn_b, tbn_rm, tbn_rv, res_mode(0 none,1 identity,2 conv), rw, rb, rbn_w, rbn_b, rbn_rm,
+          rbn_rv, stride, training"""
+
+    @staticmethod
+    def forward(ctx, x, A, PA, wab, bab, wd, bd, gbn_w, gbn_b, gbn_rm, gbn_rv, down_w, down_b, dbn_w, dbn_b, dbn_rm,
+                dbn_rv, tw, tb, tbn_w, tbn_b, tbn_rm, tbn_rv, res_mode, rw, rb, rbn_w, rbn_b, rbn_rm, rbn_rv, stride,
+                training):
+        c = _Ctx()
+        x = x.contiguous()
+        down = None if down_w is None else (down_w, down_b, dbn_w, dbn_b, dbn_rm, dbn_rv)
+        g = gcn_forward(c, x, A, PA, wab, bab, wd, bd, (gbn_w, gbn_b, gbn_rm, gbn_rv), down, training)
+        res = None if res_mode == 0 else ('identity' if res_mode == 1 else (rw, rb, rbn_w, rbn_b, rbn_rm, rbn_rv))
+        out = tcn_forward(c, g, tw, tb, (tbn_w, tbn_b, tbn_rm, tbn_rv), stride, x, res, True, training)
+        ctx.c, ctx.training, ctx.has_down, ctx.res_mode, ctx.stride = c, training, down is not None, res_mode, stride
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        _need_train(ctx.training)
+        c = ctx.c
+        dout = dout.contiguous()
+        dg, dtw, dtg, dtb, drpre, drw, drg, drb = tcn_backward(c, dout)
+        if ctx.res_mode == 1:
+            gres = gcn_backward(c, dg, extra_add=dout, extra_mask=c.t_out)
+        else:
+            gres = gcn_backward(c, dg)
+        dx, dPA, dwab, dbab, dwd, dg1, db1, dwdown, dg2, db2 = gres
+        if ctx.res_mode == 2:
+            conv_bwd_data(drpre, c.t_params[2], c.g_x.shape, ctx.stride, out=dx, accumulate=True)
+        dev = dout.device
+        zb = lambda n: torch.zeros(n, dtype=torch.float32, device=dev)  # noqa: E731
+        ctx.c = None
+        return (dx, None, dPA, dwab, dbab, dwd, zb(dwd.shape[0]), dg1, db1, None, None,
+                dwdown, zb(dwdown.shape[0]) if ctx.has_down else None, dg2, db2, None, None,
+                dtw, zb(dtw.shape[0]), dtg, dtb, None, None, None,
+                drw, zb(drw.shape[0]) if ctx.res_mode == 2 else None, drg, drb, None, None, None, None)

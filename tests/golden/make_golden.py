@@ -52,6 +52,8 @@ def sample_idx(numel, k=64):
 
 
 def pack_grads(out, named_params, prefix='g.', full_limit=40000):
+    """prefix 'g.' = the reference in fp32 (the parity target); 'g64.' = the SAME reference code run in fp64,
+    stored rounded to fp32: it measures the reference's own fp32 rounding noise per tensor."""
     for name, p in named_params:
         g = p.grad.detach().numpy().astype(np.float32)
         out[prefix + name + '.norm'] = np.float64(np.linalg.norm(g.astype(np.float64)))
@@ -108,6 +110,19 @@ def make_unit(ref, name, cin, cout, stride, residual, t, v, seed, stress):
     out['dx'] = x.grad.numpy()
     out['loss'] = np.float64(loss.item())
     pack_grads(out, unit.named_parameters())
+    # the same reference module in fp64 (noise-floor measurement)
+    unit64 = ref.TCN_GCN_unit(cin, cout, A, stride=stride, residual=residual).double()
+    unit64.load_state_dict({k: v_.double() if v_.is_floating_point() else v_ for k, v_ in sd.items()})
+    for m_ in unit64.modules():
+        if hasattr(m_, 'A') and isinstance(getattr(m_, 'A'), torch.Tensor) and not isinstance(m_.A, torch.nn.Parameter):
+            m_.A = m_.A.double()
+    unit64.train()
+    x64 = torch.from_numpy(xn).double().requires_grad_(True)
+    y64 = unit64(x64)
+    (y64 * torch.from_numpy(rn).double()).sum().backward()
+    out['y64'] = y64.detach().numpy().astype(np.float32)
+    out['dx64'] = x64.grad.numpy().astype(np.float32)
+    pack_grads(out, unit64.named_parameters(), prefix='g64.')
     for k, b in unit.state_dict().items():
         if k.endswith(('running_mean', 'running_var')):
             out['buf.' + k] = b.numpy().copy()
@@ -156,6 +171,34 @@ def make_model(ref, name, n, v, num_class, graph, seed, stress, t):
     out['logits'] = logits.detach().numpy()
     out['loss'] = np.float64(loss.item())
     pack_grads(out, model.named_parameters(), full_limit=2000)
+    model64 = ref.Model(num_class=num_class, num_point=v, num_person=2, graph=graph,
+                        graph_args=dict(labeling_mode='spatial')).double()
+    model64.load_state_dict({k: v_.double() if v_.is_floating_point() else v_ for k, v_ in sd.items()})
+    for m_ in model64.modules():
+        if hasattr(m_, 'A') and isinstance(getattr(m_, 'A'), torch.Tensor) and not isinstance(m_.A, torch.nn.Parameter):
+            m_.A = m_.A.double()
+    model64.train()
+    logits64 = model64(torch.from_numpy(xn).double())
+    torch.nn.functional.cross_entropy(logits64, torch.from_numpy(lab)).backward()
+    out['logits64'] = logits64.detach().numpy().astype(np.float32)
+    pack_grads(out, model64.named_parameters(), prefix='g64.', full_limit=2000)
+    # Conditioning of the gradients: the network has ~1e6 ReLU inputs per layer, a few of them within 1e-6 of
+    # the kink; ANY perturbation of that size (fp32 rounding, another summation order) flips their masks and
+    # moves some parameter gradients by ~1e-2 of max|g|.  Measure it with the reference itself (fp64, inputs
+    # perturbed by 1e-6 relative) and store the per-tensor band next to the gradients.
+    g64 = {k: p.grad.detach().clone() for k, p in model64.named_parameters()}
+    sens = {k: 0.0 for k in g64}
+    prng = torch.Generator().manual_seed(seed)
+    for _ in range(3):
+        model64.zero_grad()
+        xp = torch.from_numpy(xn).double()
+        xp = xp * (1.0 + 1e-6 * torch.randn(xp.shape, generator=prng, dtype=torch.float64))
+        torch.nn.functional.cross_entropy(model64(xp), torch.from_numpy(lab)).backward()
+        for k, p in model64.named_parameters():
+            d = float((p.grad - g64[k]).abs().max() / max(1e-300, float(g64[k].abs().max())))
+            sens[k] = max(sens[k], d)
+    for k, v_ in sens.items():
+        out['sens.' + k] = np.float32(v_)
     out['meta'] = np.array([n, v, num_class, seed, t], dtype=np.int64)
     out['meta.stress'] = np.float32(stress)
     np.savez_compressed(os.path.join(HERE, name + '.npz'), **out)

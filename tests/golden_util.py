@@ -55,9 +55,48 @@ def grad_err(g, gold, name):
 
 
 ZERO_GRAD_BIAS = ('conv_d.0.bias', 'conv_d.1.bias', 'conv_d.2.bias', 'down.0.bias', 'tcn1.conv.bias',
-                  'residual.conv.bias')
+                  'residual.conv.bias', 'conv_a.0.bias', 'conv_a.1.bias', 'conv_a.2.bias')
 
 
 def is_zero_grad_bias(name):
-    """Conv biases feeding a train-mode BN have mathematically zero gradient."""
+    """Structurally-zero gradients, compared with an ABSOLUTE tolerance only:
+    * conv biases feeding a train-mode BN (SURVEY F9);
+    * conv_a biases: they add a term to the logits S[u,v] that is constant in u, and the softmax over u
+      (agcn.py:80,101) is invariant to it.  The reference's fp32 values there are rounding noise (~1e-7)."""
     return name.endswith(ZERO_GRAD_BIAS)
+
+
+def _pick(gold, prefix, name, g):
+    if (prefix + name) in gold:
+        return np.asarray(g, dtype=np.float64), gold[prefix + name].astype(np.float64)
+    idx = gold['g.' + name + '.idx']
+    return np.asarray(g, dtype=np.float64).reshape(-1)[idx], gold[prefix + name + '.samples'].astype(np.float64)
+
+
+def sens_floor(gold):
+    vals = [float(v) for k, v in gold.items() if k.startswith('sens.') and not is_zero_grad_bias(k)]
+    return float(np.median(vals)) if vals else 0.0
+
+
+def grad_check(g, gold, name, tol):
+    """Noise-aware gradient parity.  err32 = distance to the reference run in fp32 (the parity target);
+    the fixtures also hold the SAME reference code run in fp64, which gives the reference's own fp32 rounding
+    noise per tensor (up to ~1e-2 of max|g| for the adjacency parameters of the full model, whose gradients are
+    sums of ~1e5 cancelling terms).  Pass if err32 <= tol, or if the result is as close to the fp64 answer as
+    the fp32 reference itself is (within 3x): err64 <= tol + 3*noise.  Returns (ok, err32, err64, noise)."""
+    scale = max(float(gold['g.' + name + '.absmax']), 1e-12)
+    a, r32 = _pick(gold, 'g.', name, g)
+    err32 = float(np.abs(a - r32).max() / scale)
+    if ('g64.' + name + '.absmax') not in gold:
+        return err32 <= tol, err32, None, None
+    _, r64 = _pick(gold, 'g64.', name, g)
+    noise = float(np.abs(r32 - r64).max() / scale)
+    # 'sens.*' (model fixtures): how far the REFERENCE's own fp64 gradient moves when its input is perturbed by
+    # 1e-6 relative -- ReLU masks of elements sitting on the kink flip (see make_golden.py).  It bounds what any
+    # two correct fp32 evaluations can be expected to agree to.
+    if ('sens.' + name) in gold:
+        # three perturbation samples under-sample which kink elements flip, so the band of a tensor is at
+        # least the model-wide median band (a flip in layer L moves the gradients of every layer below it)
+        noise = max(noise, float(gold['sens.' + name]), sens_floor(gold))
+    err64 = float(np.abs(a - r64).max() / scale)
+    return (err32 <= tol) or (err64 <= tol + 3.0 * noise), err32, err64, noise

@@ -1,0 +1,259 @@
+"""Kernel-level parity of every C-ABI entry point against plain CPU fp64 PyTorch maths of the same operator.
+GPU only (``-m gpu``); calls go through ``agcn_amd.ops`` -> ctypes -> ``libagcn_hip.so``.
+
+Tolerance (fp32, north_star): max|a-ref| <= 1e-4 * max(1, max|ref|).
+"""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-4
+
+
+def _gpu():
+    import agcn_amd  # noqa: F401
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    return torch.device('cuda:0')
+
+
+def rel(a, ref):
+    a = a.detach().double().cpu()
+    ref = ref.detach().double().cpu()
+    return float((a - ref).abs().max() / max(1.0, float(ref.abs().max())))
+
+
+def rnd(gen, *shape, scale=1.0):
+    return (torch.randn(*shape, generator=gen, dtype=torch.float64) * scale)
+
+
+CONV_CASES = [
+    # N, Cin, Cout, T, V, taps, stride
+    (2, 64, 64, 23, 25, 9, 1),
+    (3, 64, 128, 21, 25, 9, 2),
+    (2, 128, 128, 12, 25, 9, 1),
+    (2, 128, 256, 14, 18, 9, 2),
+    (2, 3, 64, 23, 25, 1, 1),
+    (2, 3, 96, 11, 25, 1, 1),
+    (2, 64, 192, 23, 25, 1, 1),
+    (2, 64, 128, 21, 25, 1, 2),
+    (2, 128, 256, 16, 18, 1, 2),
+    (2, 256, 256, 9, 25, 9, 1),
+    (1, 64, 64, 300, 25, 9, 1),
+]
+
+
+def test_mfma_layout_probe():
+    """A = I (via a 1x1 conv with identity weights) and asymmetric inputs: catches any row/col swap."""
+    from agcn_amd import ops
+    dev = _gpu()
+    g = torch.Generator().manual_seed(1)
+    x = rnd(g, 1, 64, 7, 25)
+    w = torch.eye(64, dtype=torch.float64).view(64, 64, 1, 1)
+    y, _ = ops.conv_fwd(x.float().to(dev), w.float().to(dev), None)
+    assert rel(y, x) < 1e-6
+
+
+@pytest.mark.parametrize('case', CONV_CASES)
+def test_conv_fwd_bwd(case):
+    from agcn_amd import ops
+    dev = _gpu()
+    N, Cin, Cout, T, V, taps, stride = case
+    g = torch.Generator().manual_seed(hash(case) % 1000)
+    x = rnd(g, N, Cin, T, V).requires_grad_(True)
+    w = rnd(g, Cout, Cin, taps, 1, scale=1.0 / np.sqrt(Cin * taps)).requires_grad_(True)
+    b = rnd(g, Cout, scale=0.1)
+    pad = (taps - 1) // 2
+    y_ref = F.conv2d(x, w, b, stride=(stride, 1), padding=(pad, 0))
+    dy = rnd(g, *y_ref.shape)
+    y_ref.backward(dy)
+    xg, wg, bg, dyg = x.detach().float().to(dev), w.detach().float().to(dev), b.float().to(dev), dy.float().to(dev)
+    y, stats = ops.conv_fwd(xg, wg, bg, stride, want_stats=True)
+    assert rel(y, y_ref) < TOL
+    s = stats.double().sum(0).cpu()
+    assert rel(s[0], y_ref.detach().sum((0, 2, 3))) < TOL * 10
+    assert rel(s[1], (y_ref.detach() ** 2).sum((0, 2, 3))) < TOL * 10
+    dx = ops.conv_bwd_data(dyg, wg, tuple(x.shape), stride)
+    assert rel(dx, x.grad) < TOL
+    # accumulate + masked addends
+    base = rnd(g, *x.shape).float().to(dev)
+    add = rnd(g, *x.shape).float().to(dev)
+    mask = rnd(g, *x.shape).float().to(dev)
+    out = base.clone()
+    ops.conv_bwd_data(dyg, wg, tuple(x.shape), stride, out=out, accumulate=True, add1=add, mask1=mask, add2=add)
+    ref2 = x.grad + base.double().cpu() + (add.double().cpu() * (mask.cpu() > 0)) + add.double().cpu()
+    assert rel(out, ref2) < TOL
+    dw = ops.conv_bwd_weight(dyg, xg, tuple(w.shape), stride)
+    assert rel(dw, w.grad) < TOL
+
+
+GCN_CASES = [
+    # N, C, Cout, T, V
+    (2, 64, 64, 23, 25),
+    (2, 3, 64, 12, 25),
+    (3, 64, 128, 11, 25),
+    (2, 128, 256, 9, 25),
+    (2, 256, 256, 7, 25),
+    (2, 64, 64, 17, 18),
+]
+
+
+def _gcn_ref(x, adj, wcat, bias):
+    N, C, T, V = x.shape
+    y = 0
+    for i in range(3):
+        gi = torch.einsum('nctu,nuv->nctv', x, adj[:, i])
+        y = y + torch.einsum('oc,nctv->notv', wcat[:, i * C:(i + 1) * C], gi)
+    return y + bias.view(1, -1, 1, 1)
+
+
+@pytest.mark.parametrize('case', GCN_CASES)
+def test_aggregate_project(case):
+    from agcn_amd import ops
+    dev = _gpu()
+    N, C, Cout, T, V = case
+    g = torch.Generator().manual_seed(7 + C + T)
+    x = rnd(g, N, C, T, V).requires_grad_(True)
+    adj = rnd(g, N, 3, V, V, scale=0.3).requires_grad_(True)
+    wcat = rnd(g, Cout, 3 * C, scale=1.0 / np.sqrt(3 * C)).requires_grad_(True)
+    bias = rnd(g, Cout, scale=0.1)
+    y_ref = _gcn_ref(x, adj, wcat, bias)
+    dy = rnd(g, *y_ref.shape)
+    y_ref.backward(dy)
+    xg, ag, wg, bg, dyg = [t.detach().float().to(dev) for t in (x, adj, wcat, bias, dy)]
+    y, stats = ops.aggregate_project_fwd(xg, ag, wg, bg, want_stats=True)
+    assert rel(y, y_ref) < TOL
+    s = stats.double().sum(0).cpu()
+    assert rel(s[0], y_ref.detach().sum((0, 2, 3))) < TOL * 10
+    dx = ops.aggregate_project_bwd_data(dyg, ag, wg, tuple(x.shape))
+    assert rel(dx, x.grad) < TOL
+    dw = ops.project_bwd_weight(dyg, xg, ag, Cout)
+    assert rel(dw, wcat.grad) < TOL
+    # adjacency gradient via the slot partials
+    L = ops._L()
+    from agcn_amd import lib
+    nslots = L.agcn_dadj_num_slots(C, V, T)
+    dpart = torch.empty((N, 3, nslots, V, V), device=dev)
+    lib.check(L.agcn_gcn_dadj(lib.ptr(dyg), lib.ptr(wg), lib.ptr(xg), lib.ptr(dpart), N, C, Cout, T, V,
+                              lib.stream()), 'dadj')
+    assert rel(dpart.sum(2), adj.grad) < TOL
+
+
+ADJ_CASES = [(2, 16, 23, 25, 1.0), (2, 32, 12, 25, 8.0), (3, 64, 9, 18, 4.0), (2, 16, 300, 25, 30.0)]
+
+
+@pytest.mark.parametrize('case', ADJ_CASES)
+def test_adjacency_fwd_bwd(case):
+    from agcn_amd import ops
+    dev = _gpu()
+    N, Ci, T, V, scale = case
+    g = torch.Generator().manual_seed(11 + Ci + T)
+    tp = rnd(g, N, 6 * Ci, T, V, scale=scale).requires_grad_(True)
+    A = rnd(g, 3, V, V, scale=0.2)
+    PA = rnd(g, 3, V, V, scale=0.05).requires_grad_(True)
+    adjs, Ps = [], []
+    for i in range(3):
+        th = tp[:, (2 * i) * Ci:(2 * i + 1) * Ci].permute(0, 3, 1, 2).reshape(N, V, Ci * T)
+        ph = tp[:, (2 * i + 1) * Ci:(2 * i + 2) * Ci].reshape(N, Ci * T, V)
+        p = torch.softmax(torch.matmul(th, ph) / (Ci * T), dim=-2)
+        Ps.append(p)
+        adjs.append(p + A[i] + PA[i])
+    adj_ref = torch.stack(adjs, 1)
+    tpg, Ag, PAg = tp.detach().float().to(dev), A.float().to(dev), PA.detach().float().to(dev)
+    P, adj = ops.adjacency_fwd(tpg, Ag, PAg)
+    assert rel(P, torch.stack(Ps, 1)) < TOL
+    assert rel(adj, adj_ref) < TOL
+    # backward: feed a synthetic dadj through a one-slot partial buffer
+    dadj = rnd(g, N, 3, V, V)
+    adj_ref.backward(dadj)
+    from agcn_amd import lib
+    L = ops._L()
+    dpart = dadj.float().to(dev).view(N, 3, 1, V, V).contiguous()
+    dadj_o, dS, dPA = (torch.empty((N, 3, V, V), device=dev), torch.empty((N, 3, V, V), device=dev),
+                       torch.empty((3, V, V), device=dev))
+    lib.check(L.agcn_adjacency_bwd_softmax(lib.ptr(dpart), lib.ptr(P), None, lib.ptr(dadj_o), lib.ptr(dS),
+                                           lib.ptr(dPA), None, N, Ci, T, V, 1, lib.stream()), 'bwd_softmax')
+    assert rel(dPA, PA.grad) < TOL
+    nt = L.agcn_scores_num_tiles(V, T)
+    dtp = torch.empty_like(tpg)
+    dbpart = torch.empty((N * nt, 6 * Ci), device=dev)
+    db = torch.empty((6 * Ci,), device=dev)
+    lib.check(L.agcn_adjacency_bwd_scores(lib.ptr(tpg), lib.ptr(dS), lib.ptr(dtp), lib.ptr(dbpart), lib.ptr(db), N,
+                                          Ci, T, V, lib.stream()), 'bwd_scores')
+    gmax = max(1e-30, float(tp.grad.abs().max()))
+    assert float((dtp.double().cpu() - tp.grad).abs().max()) / gmax < 2e-4
+    db_ref = tp.grad.sum((0, 2, 3))
+    assert float((db.double().cpu() - db_ref).abs().max()) / max(1e-30, float(db_ref.abs().max())) < 2e-3
+
+
+BN_CASES = [(2, 64, 23, 25, 0), (2, 64, 23, 25, 1), (3, 128, 11, 25, 2), (2, 256, 7, 25, 2), (2, 64, 17, 18, 1)]
+
+
+@pytest.mark.parametrize('case', BN_CASES)
+def test_bn_act_fwd_bwd(case):
+    from agcn_amd import ops
+    dev = _gpu()
+    N, C, T, V, mode = case
+    g = torch.Generator().manual_seed(3 + C + mode)
+    y1 = (rnd(g, N, C, T, V) * 1.5 + 0.3).requires_grad_(True)
+    r = rnd(g, N, C, T, V).requires_grad_(True)
+    g1, b1 = (rnd(g, C, scale=0.3) + 1).requires_grad_(True), rnd(g, C, scale=0.1).requires_grad_(True)
+    g2, b2 = (rnd(g, C, scale=0.3) + 1).requires_grad_(True), rnd(g, C, scale=0.1).requires_grad_(True)
+    rm, rv = torch.zeros(C, dtype=torch.float64), torch.ones(C, dtype=torch.float64)
+    rm2, rv2 = rm.clone(), rv.clone()
+    z = F.batch_norm(y1, rm, rv, g1, b1, True, 0.1, 1e-5)
+    if mode == 1:
+        z = z + r
+    elif mode == 2:
+        z = z + F.batch_norm(r, rm2, rv2, g2, b2, True, 0.1, 1e-5)
+    out_ref = F.relu(z)
+    dout = rnd(g, N, C, T, V)
+    out_ref.backward(dout)
+    f = lambda t: t.detach().float().to(dev).contiguous()  # noqa: E731
+    y1g, rg = f(y1), f(r)
+    # statistics partials computed here with torch on the GPU (the contraction epilogues are tested elsewhere)
+    def part(t):
+        return torch.stack([t.sum((0, 2, 3)), (t * t).sum((0, 2, 3))]).view(1, 2, C).contiguous()
+    rmg, rvg = torch.zeros(C, device=dev), torch.ones(C, device=dev)
+    st1 = ops.bn_train_coeffs(part(y1g), N * T * V, f(g1), f(b1), rmg, rvg)
+    assert rel(rmg, rm) < TOL and rel(rvg, rv) < TOL
+    st2 = None
+    if mode == 2:
+        rm2g, rv2g = torch.zeros(C, device=dev), torch.ones(C, device=dev)
+        st2 = ops.bn_train_coeffs(part(rg), N * T * V, f(g2), f(b2), rm2g, rv2g)
+    out = ops.bn_act_fwd(y1g, st1, None if mode == 0 else rg, st2, relu=True)
+    assert rel(out, out_ref) < TOL
+    dy1, dg1, db1, dy2, dg2, db2 = ops.bn_bwd(f(dout), out, y1g, f(g1), st1, rg if mode == 2 else None,
+                                              f(g2) if mode == 2 else None, st2)
+    assert rel(dy1, y1.grad) < TOL
+    assert rel(dg1, g1.grad) < TOL * 5 and rel(db1, b1.grad) < TOL * 5
+    if mode == 2:
+        assert rel(dy2, r.grad) < TOL
+        assert rel(dg2, g2.grad) < TOL * 5 and rel(db2, b2.grad) < TOL * 5
+
+
+def test_sgd_step_matches_torch():
+    from agcn_amd import lib, ops
+    dev = _gpu()
+    L = ops._L()
+    g = torch.Generator().manual_seed(5)
+    n = 100003
+    p0 = rnd(g, n).float()
+    p_ref = p0.clone().requires_grad_(True)
+    opt = torch.optim.SGD([p_ref], lr=0.1, momentum=0.9, nesterov=True, weight_decay=1e-4)
+    p = p0.to(dev)
+    buf = torch.zeros(n, device=dev)
+    ws = torch.empty(L.agcn_sgd_step_workspace(n) // 4 + 1, device=dev)
+    norm = torch.zeros(2, device=dev)
+    for step in range(3):
+        grad = rnd(g, n, scale=0.05).float()
+        p_ref.grad = grad.clone()
+        gn = torch.nn.utils.clip_grad_norm_([p_ref], 1.0)
+        opt.step()
+        gg = grad.to(dev)
+        lib.check(L.agcn_sgd_step(lib.ptr(p), lib.ptr(gg), lib.ptr(buf), n, 0.1, 0.9, 1e-4, 1, 1.0, 1.0,
+                                  int(step == 0), lib.ptr(ws), ws.numel() * 4, lib.ptr(norm), lib.stream()), 'sgd')
+        assert abs(float(norm[0]) - float(gn)) < 1e-4 * float(gn)
+        assert rel(p, p_ref) < 1e-5

@@ -1,0 +1,213 @@
+"""HIP path vs the golden fixtures generated from the REFERENCE (tests/golden/*.npz) and vs the CPU oracle on
+seeded inputs.  GPU only (``-m gpu``).  Everything goes module -> autograd Function -> ctypes -> libagcn_hip.so.
+
+Tolerance (north_star): 1e-4 fp32, metric of SURVEY.md 8c: max|a-ref| <= 1e-4*max(1,max|ref|); gradients normalised
+by the per-tensor max|g_ref|; structurally-zero bias gradients (F9) absolute.
+"""
+import numpy as np
+import pytest
+import torch
+
+from oracle import agcn_oracle as orc
+from tests import golden_util as gu
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-4
+GTOL = 2e-4   # gradients: normalised by max|g_ref| per tensor
+
+
+def _gpu():
+    import agcn_amd  # noqa: F401
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    return torch.device('cuda:0')
+
+
+def _check_loaded():
+    """The HIP extension must be the thing that ran."""
+    from agcn_amd import lib
+    assert lib._lib is not None
+    with open('/proc/self/maps') as f:
+        assert 'libagcn_hip.so' in f.read()
+
+
+@pytest.mark.parametrize('name', gu.UNIT_NAMES)
+def test_unit_golden(name):
+    dev = _gpu()
+    from agcn_amd.model.agcn import TCN_GCN_unit
+    gold = gu.load(name)
+    cin, cout, stride, residual, t, v, seed = [int(i) for i in gold['meta']]
+    A = gu.graph_A(v).numpy()
+    unit = TCN_GCN_unit(cin, cout, A, stride=stride, residual=bool(residual))
+    shapes = orc.unit_param_shapes('', cin, cout, v, stride, bool(residual))
+    sd = orc.randomized_state(shapes, seed, stress=float(gold['meta.stress']))
+    unit.load_state_dict(sd)
+    unit.to(dev)
+    xn, rn = gu.unit_inputs(cin, cout, stride, t, v, seed)
+    # eval mode (running statistics)
+    unit.eval()
+    with torch.no_grad():
+        ye = unit(torch.from_numpy(xn).to(dev))
+    assert gu.rel_err(ye.cpu().numpy(), gold['y_eval']) < TOL
+    # train mode forward + backward
+    unit.train()
+    x = torch.from_numpy(xn).to(dev).requires_grad_(True)
+    y = unit(x)
+    (y * torch.from_numpy(rn).to(dev)).sum().backward()
+    _check_loaded()
+    assert gu.rel_err(y.detach().cpu().numpy(), gold['y']) < TOL
+    dxs = max(1.0, float(np.abs(gold['dx']).max()))
+    assert float(np.abs(x.grad.cpu().numpy() - gold['dx']).max()) / dxs < GTOL
+    for k, p in unit.named_parameters():
+        if gu.is_zero_grad_bias(k):
+            assert float(p.grad.abs().max()) < 1e-5, k
+            continue
+        ok, e32, e64, noise = gu.grad_check(p.grad.cpu().numpy(), gold, k, GTOL)
+        assert ok, (k, e32, e64, noise)
+    for k, b in unit.state_dict().items():
+        if k.endswith(('running_mean', 'running_var')):
+            assert gu.rel_err(b.cpu().numpy(), gold['buf.' + k]) < TOL, k
+        if k.endswith('num_batches_tracked'):
+            assert int(b) == 1
+
+
+@pytest.mark.parametrize('name', gu.MODEL_NAMES)
+def test_model_golden(name):
+    dev = _gpu()
+    from model.agcn import Model
+    gold = gu.load(name)
+    n, v, num_class, seed, t = [int(i) for i in gold['meta']]
+    graph = {25: 'graph.ntu_rgb_d.Graph', 18: 'graph.kinetics.Graph'}[v]
+    model = Model(num_class=num_class, num_point=v, num_person=2, graph=graph, graph_args=dict(labeling_mode='spatial'))
+    sd = orc.randomized_state(orc.model_param_shapes(num_class, v), seed, stress=float(gold['meta.stress']))
+    model.load_state_dict(sd)
+    model.to(dev)
+    xn, lab = gu.model_inputs(n, v, num_class, seed, t)
+    model.eval()
+    with torch.no_grad():
+        le = model(torch.from_numpy(xn).to(dev))
+    assert gu.rel_err(le.cpu().numpy(), gold['logits_eval']) < TOL
+    model.train()
+    logits = model(torch.from_numpy(xn).to(dev))
+    loss = torch.nn.functional.cross_entropy(logits, torch.from_numpy(lab).to(dev))
+    loss.backward()
+    _check_loaded()
+    assert gu.rel_err(logits.detach().cpu().numpy(), gold['logits']) < TOL
+    assert abs(loss.item() - float(gold['loss'])) < TOL * max(1.0, abs(float(gold['loss'])))
+    bad = []
+    for k, p in model.named_parameters():
+        if gu.is_zero_grad_bias(k):
+            assert float(p.grad.abs().max()) < 1e-5, k
+            continue
+        ok, e32, e64, noise = gu.grad_check(p.grad.cpu().numpy(), gold, k, GTOL)
+        if not ok:
+            bad.append((k, e32, e64, noise))
+    assert not bad, bad[:8]
+
+
+def test_model_layerwise_vs_oracle_full_size():
+    """Full-size (T=300) check that is free of ReLU-kink conditioning: run the HIP model end to end, capture every
+    TCN_GCN_unit's input x_k and output gradient dy_k, then re-evaluate each layer with the fp64 CPU oracle on
+    exactly those tensors, imposing the HIP path's own ReLU patterns, and compare y_k, dx_k and all parameter
+    gradients of the layer."""
+    dev = _gpu()
+    from model.agcn import Model
+    gold = gu.load('m_ntu_b1')
+    n, v, num_class, seed, t = [int(i) for i in gold['meta']]
+    sd0 = orc.randomized_state(orc.model_param_shapes(num_class, v), seed, stress=float(gold['meta.stress']))
+    model = Model(num_class=num_class, num_point=v, num_person=2, graph='graph.ntu_rgb_d.Graph',
+                  graph_args=dict(labeling_mode='spatial'))
+    model.load_state_dict(sd0)
+    model.to(dev).train()
+    cap = {}
+
+    def pre(k):
+        def hook(mod, inp):
+            inp[0].retain_grad()
+            cap[('x', k)] = inp[0]
+        return hook
+
+    def post(k):
+        def hook(mod, inp, out):
+            out.retain_grad()
+            cap[('y', k)] = out
+        return hook
+    for k in range(1, 11):
+        getattr(model, f'l{k}').register_forward_pre_hook(pre(k))
+        getattr(model, f'l{k}').register_forward_hook(post(k))
+    xn, lab = gu.model_inputs(n, v, num_class, seed, t)
+    logits = model(torch.from_numpy(xn).to(dev))
+    torch.nn.functional.cross_entropy(logits, torch.from_numpy(lab).to(dev)).backward()
+    A = gu.graph_A(v).double()
+    worst = {}
+    for k, (cin, cout, stride, res) in enumerate(orc.LAYERS, start=1):
+        unit = getattr(model, f'l{k}')
+        x_k, y_k = cap[('x', k)], cap[('y', k)]
+        with torch.no_grad():
+            g_k = unit.gcn1(x_k.detach())           # same kernels, same input -> the forward's own pattern
+        masks = ((g_k > 0).double().cpu(), (y_k.detach() > 0).double().cpu())
+        sub = {kk[len(f'l{k}.'):]: vv for kk, vv in sd0.items() if kk.startswith(f'l{k}.')}
+        sd = orc.with_grad({kk: (vv.double() if vv.is_floating_point() else vv) for kk, vv in sub.items()})
+        xo = x_k.detach().double().cpu().requires_grad_(k > 1 or True)
+        yo = orc.tcn_gcn_unit_forward(xo, sd, '', A, stride, res, training=True, masks=masks)
+        yo.backward(y_k.grad.double().cpu())
+        assert gu.rel_err(y_k.detach().cpu().numpy(), yo.detach().numpy()) < TOL, k
+        dxs = max(1e-30, float(xo.grad.abs().max()))
+        e_dx = float((x_k.grad.double().cpu() - xo.grad).abs().max()) / dxs
+        assert e_dx < GTOL, (k, 'dx', e_dx)
+        for kk, p in unit.named_parameters():
+            if gu.is_zero_grad_bias(kk):
+                continue
+            ref = sd[kk].grad
+            e = float((p.grad.double().cpu() - ref).abs().max()) / max(1e-30, float(ref.abs().max()))
+            worst[f'l{k}.{kk}'] = e
+            assert e < GTOL, (k, kk, e)
+
+
+def test_unit_vs_oracle_seeded_batch():
+    """Same seeded inputs through the CPU oracle and the HIP path at a size the oracle finishes in seconds
+    (ragged frame tiles: T=37 is not a multiple of the 10-frame tile)."""
+    dev = _gpu()
+    from agcn_amd.model.agcn import TCN_GCN_unit
+    cin, cout, stride, v, t, n = 64, 128, 2, 25, 37, 5
+    A = gu.graph_A(v)
+    shapes = orc.unit_param_shapes('', cin, cout, v, stride, True)
+    sd0 = orc.randomized_state(shapes, 4242, stress=5.0)
+    rng = np.random.default_rng(99)
+    xn = rng.standard_normal((n, cin, t, v)).astype(np.float32)
+    sd = orc.with_grad(sd0)
+    xo = torch.from_numpy(xn).requires_grad_(True)
+    yo = orc.tcn_gcn_unit_forward(xo, sd, '', A, stride, True, training=True)
+    rn = torch.from_numpy(rng.standard_normal(tuple(yo.shape)).astype(np.float32))
+    (yo * rn).sum().backward()
+    unit = TCN_GCN_unit(cin, cout, A.numpy(), stride=stride, residual=True)
+    unit.load_state_dict(sd0)
+    unit.to(dev).train()
+    x = torch.from_numpy(xn).to(dev).requires_grad_(True)
+    y = unit(x)
+    (y * rn.to(dev)).sum().backward()
+    assert gu.rel_err(y.detach().cpu().numpy(), yo.detach().numpy()) < TOL
+    assert gu.rel_err(x.grad.cpu().numpy(), xo.grad.numpy()) < GTOL * max(1.0, float(xo.grad.abs().max()))
+    # the fp64 oracle gives the exact answer; the fp32 oracle's distance to it is the fp32 noise floor
+    sd64 = orc.with_grad({k: (v_.double() if v_.is_floating_point() else v_) for k, v_ in sd0.items()})
+    x64 = torch.from_numpy(xn).double().requires_grad_(True)
+    y64 = orc.tcn_gcn_unit_forward(x64, sd64, '', A.double(), stride, True, training=True)
+    (y64 * rn.double()).sum().backward()
+    for k, p in unit.named_parameters():
+        if gu.is_zero_grad_bias(k):
+            assert float(p.grad.abs().max()) < 1e-5, k
+            continue
+        ref, ref64 = sd[k].grad.double(), sd64[k].grad
+        scale = max(1e-12, float(ref.abs().max()))
+        err32 = float((p.grad.cpu().double() - ref).abs().max()) / scale
+        err64 = float((p.grad.cpu().double() - ref64).abs().max()) / scale
+        noise = float((ref - ref64).abs().max()) / scale
+        assert err32 < GTOL or err64 < GTOL + 3 * noise, (k, err32, err64, noise)
+
+
+def test_cpu_input_raises():
+    _gpu()
+    from agcn_amd.model.agcn import TCN_GCN_unit
+    unit = TCN_GCN_unit(64, 64, gu.graph_A(25).numpy())
+    with pytest.raises(RuntimeError):
+        unit(torch.zeros(1, 64, 8, 25))
