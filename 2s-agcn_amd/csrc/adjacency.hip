@@ -38,14 +38,22 @@ scores_fwd_kernel(const float* __restrict__ tp, float* __restrict__ spart, int N
   const int lc = min(lr, V - 1);
   for (int c0 = 0; c0 < Ci; c0 += SC_CK) {
     __syncthreads();
-    for (int cl = wave; cl < SC_CK; cl += 4) {
-      const bool ok = (c0 + cl) < Ci;
-      const float* s1 = th_base + (long)(c0 + (ok ? cl : 0)) * P;
-      const float* s2 = ph_base + (long)(c0 + (ok ? cl : 0)) * P;
-      for (int q = lane; q < ttv; q += 64) {
-        const bool v = ok && q < nvalid;
-        Th[cl * ttv + q] = v ? s1[q] : 0.f;
-        Ph[cl * ttv + q] = v ? s2[q] : 0.f;
+    for (int q = lane; q < ttv; q += 64) {          // 4 rows x 2 tensors in flight per lane
+      float v1[SC_CK / 4], v2[SC_CK / 4];
+#pragma unroll
+      for (int j = 0; j < SC_CK / 4; ++j) {
+        const int cl = wave + 4 * j;
+        const bool ok = (c0 + cl) < Ci && q < nvalid;
+        const long o = (long)(c0 + ((c0 + cl) < Ci ? cl : 0)) * P + (ok ? q : 0);
+        const float t1 = th_base[o], t2 = ph_base[o];
+        v1[j] = ok ? t1 : 0.f;
+        v2[j] = ok ? t2 : 0.f;
+      }
+#pragma unroll
+      for (int j = 0; j < SC_CK / 4; ++j) {
+        const int cl = wave + 4 * j;
+        Th[cl * ttv + q] = v1[j];
+        Ph[cl * ttv + q] = v2[j];
       }
     }
     __syncthreads();
@@ -189,14 +197,23 @@ scores_bwd_kernel(const float* __restrict__ tp, const float* __restrict__ dS, fl
   const int nrt = (nrows + 31) >> 5;
   for (int c0 = 0; c0 < Ci; c0 += SC_CK) {
     __syncthreads();
-    for (int cl = wave; cl < SC_CK; cl += 4) {
-      const bool ok = (c0 + cl) < Ci;
-      const float* s1 = tp + (row0 + c0 + (ok ? cl : 0)) * P + (long)t0 * V;
-      const float* s2 = s1 + (long)Ci * P;
-      for (int q = lane; q < ttv; q += 64) {
-        const bool v = ok && q < nvalid;
-        Th[cl * ttv + q] = v ? s1[q] : 0.f;
-        Ph[cl * ttv + q] = v ? s2[q] : 0.f;
+    for (int q = lane; q < ttv; q += 64) {          // 4 rows x 2 tensors in flight per lane
+      float v1[SC_CK / 4], v2[SC_CK / 4];
+#pragma unroll
+      for (int j = 0; j < SC_CK / 4; ++j) {
+        const int cl = wave + 4 * j;
+        const bool okr = (c0 + cl) < Ci;
+        const bool ok = okr && q < nvalid;
+        const float* s1 = tp + (row0 + c0 + (okr ? cl : 0)) * P + (long)t0 * V;
+        const float t1 = s1[ok ? q : 0], t2 = s1[(long)Ci * P + (ok ? q : 0)];
+        v1[j] = ok ? t1 : 0.f;
+        v2[j] = ok ? t2 : 0.f;
+      }
+#pragma unroll
+      for (int j = 0; j < SC_CK / 4; ++j) {
+        const int cl = wave + 4 * j;
+        Th[cl * ttv + q] = v1[j];
+        Ph[cl * ttv + q] = v2[j];
       }
     }
     __syncthreads();
@@ -239,15 +256,6 @@ scores_bwd_kernel(const float* __restrict__ tp, const float* __restrict__ dS, fl
       }
     }
   }
-}
-
-// out[j] = sum_slot part[slot][j]
-__global__ void slot_reduce_kernel(const float* __restrict__ part, float* __restrict__ out, int nslots, int width) {
-  const int j = blockIdx.x * blockDim.x + threadIdx.x;
-  if (j >= width) return;
-  float s = 0.f;
-  for (int k = 0; k < nslots; ++k) s += part[(long)k * width + j];
-  out[j] = s;
 }
 
 inline int sc_tile_frames(int V, int T) {
@@ -295,10 +303,11 @@ int agcn_adjacency_bwd_softmax(const float* dadj_part, const float* P, const flo
   return agcn_check_launch();
 }
 
-// dtp: (N,6Ci,T*V) ; dbpart: (N*ntiles, 6Ci) scratch ; db: (6Ci)
-int agcn_adjacency_bwd_scores(const float* tp, const float* dS, float* dtp, float* dbpart, float* db, int N, int Ci,
-                              int T, int V, void* stream) {
-  if (!tp || !dS || !dtp || !dbpart || !db || N <= 0 || Ci <= 0 || T <= 0 || V <= 0 || V > 32) return AGCN_ERR_ARG;
+// dtp: (N,6Ci,T*V) ; dbpart: (N*ntiles, 6Ci) scratch ; scratch: agcn_colsum_scratch_bytes(6Ci) ; db: (6Ci)
+int agcn_adjacency_bwd_scores(const float* tp, const float* dS, float* dtp, float* dbpart, void* scratch, float* db,
+                              int N, int Ci, int T, int V, void* stream) {
+  if (!tp || !dS || !dtp || !dbpart || !scratch || !db || N <= 0 || Ci <= 0 || T <= 0 || V <= 0 || V > 32)
+    return AGCN_ERR_ARG;
   hipStream_t s = (hipStream_t)stream;
   const int tt = sc_tile_frames(V, T), ntiles = (T + tt - 1) / tt;
   const int VP = 2 * ((V + 1) / 2);
@@ -307,10 +316,7 @@ int agcn_adjacency_bwd_scores(const float* tp, const float* dS, float* dtp, floa
                      ntiles);
   int rc = agcn_check_launch();
   if (rc) return rc;
-  const int width = 6 * Ci;
-  hipLaunchKernelGGL(slot_reduce_kernel, dim3((width + 255) / 256), dim3(256), 0, s, (const float*)dbpart, db,
-                     N * ntiles, width);
-  return agcn_check_launch();
+  return agcn_colsum(dbpart, N * ntiles, 6 * Ci, scratch, db, stream);
 }
 
 }  // extern "C"

@@ -36,6 +36,9 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
   return base + k;
 }
 
+extern "C" size_t agcn_colsum_scratch_bytes(int W);
+extern "C" int agcn_colsum(const float* X, int nslots, int W, void* scratch, float* out, void* stream);
+
 static inline int agcn_check_launch() {
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? AGCN_OK : (int)e;

@@ -6,8 +6,35 @@
 
 namespace {
 
+constexpr int RG = 64;   // slot groups of the two-stage column reduction
+
+// stage 1 of a column sum X[nslots][W] -> partial[RG][W] (double): grid (ceil(W/64), RG), 64 columns x 4 slot lanes
+__global__ void __launch_bounds__(256)
+colsum_stage1_kernel(const float* __restrict__ X, int nslots, int W, int per_group, double* __restrict__ partial) {
+  __shared__ double red[4][64];
+  const int col = blockIdx.x * 64 + (threadIdx.x & 63), sub = threadIdx.x >> 6;
+  const int g = blockIdx.y;
+  const int s_end = min(nslots, (g + 1) * per_group);
+  double acc = 0.0;
+  if (col < W)
+    for (int s = g * per_group + sub; s < s_end; s += 4) acc += (double)X[(long)s * W + col];
+  red[sub][threadIdx.x & 63] = acc;
+  __syncthreads();
+  if (sub == 0 && col < W)
+    partial[(long)g * W + col] = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+}
+
+__global__ void colsum_stage2_kernel(const double* __restrict__ partial, int W, float* __restrict__ out) {
+  const int col = blockIdx.x * blockDim.x + threadIdx.x;
+  if (col >= W) return;
+  double s = 0.0;
+  for (int g = 0; g < RG; ++g) s += partial[(long)g * W + col];
+  out[col] = (float)s;
+}
+
 // ---- forward statistics -> mean / invstd / folded affine, running-stat update (momentum, unbiased var) ----
-__global__ void bn_stats_finalize_kernel(const float* __restrict__ part, int nslots, int C, double count,
+// partial: [RG][2][C] doubles from colsum_stage1 over the [nslots][2][C] slab of the contraction epilogue
+__global__ void bn_stats_finalize_kernel(const double* __restrict__ partial, int C, double count,
                                          const float* __restrict__ gamma, const float* __restrict__ beta,
                                          float* __restrict__ rmean, float* __restrict__ rvar, float momentum,
                                          float eps, float* __restrict__ mean_out, float* __restrict__ invstd_out,
@@ -15,9 +42,9 @@ __global__ void bn_stats_finalize_kernel(const float* __restrict__ part, int nsl
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= C) return;
   double s = 0.0, ss = 0.0;
-  for (int k = 0; k < nslots; ++k) {
-    s += (double)part[((long)k * 2 + 0) * C + c];
-    ss += (double)part[((long)k * 2 + 1) * C + c];
+  for (int g = 0; g < RG; ++g) {
+    s += partial[((long)g * 2 + 0) * C + c];
+    ss += partial[((long)g * 2 + 1) * C + c];
   }
   const double mean = s / count;
   double var = ss / count - mean * mean;
@@ -189,13 +216,38 @@ inline unsigned ew_grid(unsigned total4) {
 
 extern "C" {
 
-// part: [nslots][2][C] from the contraction epilogue ; count = N*T*V ; rmean/rvar may be null (no update)
+// doubles of scratch the two-stage column reductions need for a width-W slab
+size_t agcn_colsum_scratch_bytes(int W) { return sizeof(double) * (size_t)RG * (size_t)W; }
+
+// out[w] = sum_s X[s][w], fixed summation order (bitwise reproducible), double accumulation
+int agcn_colsum(const float* X, int nslots, int W, void* scratch, float* out, void* stream) {
+  if (!X || !scratch || !out || nslots <= 0 || W <= 0) return AGCN_ERR_ARG;
+  hipStream_t s = (hipStream_t)stream;
+  const int per_group = (nslots + RG - 1) / RG;
+  hipLaunchKernelGGL(colsum_stage1_kernel, dim3((W + 63) / 64, RG), dim3(256), 0, s, X, nslots, W, per_group,
+                     (double*)scratch);
+  int rc = agcn_check_launch();
+  if (rc) return rc;
+  hipLaunchKernelGGL(colsum_stage2_kernel, dim3((W + 255) / 256), dim3(256), 0, s, (const double*)scratch, W, out);
+  return agcn_check_launch();
+}
+
+// part: [nslots][2][C] from the contraction epilogue ; count = N*T*V ; rmean/rvar may be null (no update);
+// scratch: agcn_colsum_scratch_bytes(2*C) bytes
 int agcn_bn_stats_finalize(const float* part, int nslots, int C, double count, const float* gamma, const float* beta,
-                           float* running_mean, float* running_var, float momentum, float eps, float* mean,
-                           float* invstd, float* scale, float* shift, void* stream) {
-  if (!part || !gamma || !beta || !mean || !invstd || !scale || !shift || C <= 0 || nslots <= 0) return AGCN_ERR_ARG;
-  hipLaunchKernelGGL(bn_stats_finalize_kernel, dim3((C + 63) / 64), dim3(64), 0, (hipStream_t)stream, part, nslots, C,
-                     count, gamma, beta, running_mean, running_var, momentum, eps, mean, invstd, scale, shift);
+                           float* running_mean, float* running_var, float momentum, float eps, void* scratch,
+                           float* mean, float* invstd, float* scale, float* shift, void* stream) {
+  if (!part || !gamma || !beta || !scratch || !mean || !invstd || !scale || !shift || C <= 0 || nslots <= 0)
+    return AGCN_ERR_ARG;
+  hipStream_t s = (hipStream_t)stream;
+  const int W = 2 * C;
+  const int per_group = (nslots + RG - 1) / RG;
+  hipLaunchKernelGGL(colsum_stage1_kernel, dim3((W + 63) / 64, RG), dim3(256), 0, s, part, nslots, W, per_group,
+                     (double*)scratch);
+  int rc = agcn_check_launch();
+  if (rc) return rc;
+  hipLaunchKernelGGL(bn_stats_finalize_kernel, dim3((C + 63) / 64), dim3(64), 0, s, (const double*)scratch, C, count,
+                     gamma, beta, running_mean, running_var, momentum, eps, mean, invstd, scale, shift);
   return agcn_check_launch();
 }
 

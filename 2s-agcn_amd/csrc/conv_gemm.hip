@@ -118,39 +118,79 @@ __global__ void __launch_bounds__(WM* WN * 64) conv_gemm_kernel(const ConvGemmAr
   for (int ch = 0; ch < nchunks; ++ch) {
     const int kc0 = ch * CK;
     __syncthreads();   // every wave is done reading the previous chunk
-    // ---- stage A chunk: Aw[kk][m_local] ----
-    if (MODE == 0) {
-      for (int e = tid; e < BM * KK; e += NT) {
-        const int ml = e / KK, kk = e - ml * KK;
-        const int i = kk / (CK * TAPS), r = kk - i * (CK * TAPS);
-        const int kcl = r / TAPS, tap = r - kcl * TAPS;
-        const int m = m0 + ml, kc = kc0 + kcl;
-        float val = 0.f;
-        if (m < a.M && kc < a.Kinner) val = a.w[(long)m * a.sa_m + (long)i * a.sa_i + (long)kc * a.sa_c + tap];
-        Aw[kk * BMP + ml] = val;
-      }
-    } else {
-      for (int e = tid; e < BM * KK; e += NT) {
-        const int kkc = e / (BM * TAPS), r = e - kkc * (BM * TAPS);
-        const int ml = r / TAPS, gt = r - ml * TAPS;
-        const int i = kkc / CK, kcl = kkc - i * CK;
-        const int m = m0 + ml, kc = kc0 + kcl;
-        float val = 0.f;
-        if (m < a.M && kc < a.Kinner) val = a.w[(long)m * a.sa_m + (long)i * a.sa_i + (long)kc * a.sa_c + gt];
-        Aw[(kkc * TAPS + (TAPS - 1 - gt)) * BMP + ml] = val;
+    // ---- stage A chunk: Aw[kk][m_local]; loads are issued in batches of AU before any LDS store so that
+    //      AU global requests are in flight per lane (a load->store->load chain is latency-bound) ----
+    {
+      constexpr int AU = 6;
+      constexpr int TOTAL = BM * KK;
+      for (int e0 = tid; e0 < TOTAL; e0 += NT * AU) {
+        float val[AU];
+        int dst[AU];
+#pragma unroll
+        for (int u = 0; u < AU; ++u) {
+          const int e = min(e0 + u * NT, TOTAL - 1);
+          int ml, i, kcl, gt, row;
+          if (MODE == 0) {
+            ml = e / KK;
+            const int kk = e - ml * KK;
+            i = kk / (CK * TAPS);
+            const int r = kk - i * (CK * TAPS);
+            kcl = r / TAPS;
+            gt = r - kcl * TAPS;
+            row = kk;
+          } else {
+            const int kkc = e / (BM * TAPS), r = e - kkc * (BM * TAPS);
+            ml = r / TAPS;
+            gt = r - ml * TAPS;
+            i = kkc / CK;
+            kcl = kkc - i * CK;
+            row = kkc * TAPS + (TAPS - 1 - gt);
+          }
+          const int m = m0 + ml, kc = kc0 + kcl;
+          const bool ok = m < a.M && kc < a.Kinner;
+          const long gi = ok ? ((long)m * a.sa_m + (long)i * a.sa_i + (long)kc * a.sa_c + gt) : 0;
+          const float t = a.w[gi];
+          val[u] = ok ? t : 0.f;
+          dst[u] = row * BMP + ml;
+        }
+#pragma unroll
+        for (int u = 0; u < AU; ++u)
+          if (e0 + u * NT < TOTAL) Aw[dst[u]] = val[u];
       }
     }
     // ---- stage B source window: Bx[kc_local][r], r = (f - f0)*V + v, zero outside [0,T_src) ----
-    for (int kcl = wave; kcl < CK; kcl += NW) {
-      const int kc = kc0 + kcl;
-      const bool rowok = kc < a.Kinner;
-      const float* src = a.in + ((long)n * a.in_rows + (rowok ? kc : 0)) * Psrc;
+    {
+      constexpr int RPW = (CK + NW - 1) / NW;            // rows per wave
+      constexpr int RU = (RPW >= 8) ? 1 : (8 / RPW);     // column blocks in flight per row
+      const float* rowp[RPW];
+      bool rok[RPW];
+#pragma unroll
+      for (int j = 0; j < RPW; ++j) {
+        const int kcl = wave + j * NW;
+        rok[j] = kcl < CK && (kc0 + kcl) < a.Kinner;
+        rowp[j] = a.in + ((long)n * a.in_rows + (rok[j] ? (kc0 + kcl) : 0)) * Psrc;
+      }
       const int g0 = f0 * V;
-      for (int r = lane; r < WL; r += 64) {
-        const int gp = g0 + r;
-        float val = 0.f;
-        if (rowok && gp >= 0 && gp < Psrc) val = src[gp];
-        Bx[kcl * WLP + r] = val;
+      for (int r0 = lane; r0 < WL; r0 += 64 * RU) {
+        float val[RPW][RU];
+#pragma unroll
+        for (int j = 0; j < RPW; ++j)
+#pragma unroll
+          for (int u = 0; u < RU; ++u) {
+            const int r = r0 + 64 * u;
+            const int gp = g0 + r;
+            const bool ok = rok[j] && r < WL && gp >= 0 && gp < Psrc;
+            const float t = rowp[j][ok ? gp : 0];
+            val[j][u] = ok ? t : 0.f;
+          }
+#pragma unroll
+        for (int j = 0; j < RPW; ++j)
+#pragma unroll
+          for (int u = 0; u < RU; ++u) {
+            const int r = r0 + 64 * u;
+            const int kcl = wave + j * NW;
+            if (kcl < CK && r < WL) Bx[kcl * WLP + r] = val[j][u];
+          }
       }
     }
     __syncthreads();

@@ -27,6 +27,7 @@ template <int TAPS, int AGG, int MW, int CW, int TMr, int TNr>
 __global__ void __launch_bounds__(MW* CW * 64) conv_wgrad_kernel(const WgradArgs a) {
   constexpr int NW = MW * CW, NT = NW * 64;
   constexpr int BM = MW * TMr * 32, CB = CW * TNr * 32;
+  static_assert((BM / NW) % 8 == 0 && (CB / NW) % 8 == 0, "staging batches rows by 8");
   constexpr int NSUB = AGG ? 3 : 1;
   constexpr int PAD = (TAPS - 1) / 2;
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -77,22 +78,74 @@ __global__ void __launch_bounds__(MW* CW * 64) conv_wgrad_kernel(const WgradArgs
     const int nvalid = min(tt, a.T_out - t0) * V;
     const int f0 = AGG ? t0 : (t0 * a.stride - PAD);
     __syncthreads();
-    // ---- stage dy tile: Da[m_local][q] (zero beyond the valid positions, incl. the pad column) ----
-    for (int ml = wave; ml < BM; ml += NW) {
-      const int m = m0 + ml;
-      const bool ok = m < a.M;
-      const float* src = a.dy + ((long)n * a.M + (ok ? m : 0)) * Pout + (long)t0 * V;
-      for (int q = lane; q < DAP; q += 64) Da[ml * DAP + q] = (ok && q < nvalid) ? src[q] : 0.f;
+    // ---- stage dy tile: Da[m_local][q] (zero beyond the valid positions, incl. the pad column).
+    //      Loads are issued in batches (8 rows x column blocks) before the LDS stores: many requests in flight. ----
+    {
+      constexpr int RPW = BM / NW;        // rows per wave (16 or 32)
+      constexpr int RG = 8;               // rows per batch
+      const long dybase = (long)n * a.M * Pout + (long)t0 * V;
+      for (int jg = 0; jg < RPW; jg += RG) {
+        for (int q0 = lane; q0 < DAP; q0 += 128) {
+          float val[RG][2];
+#pragma unroll
+          for (int j = 0; j < RG; ++j) {
+            const int ml = wave + (jg + j) * NW;
+            const int m = m0 + ml;
+            const bool okr = m < a.M;
+            const float* src = a.dy + dybase + (long)(okr ? m : 0) * Pout;
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+              const int q = q0 + 64 * u;
+              const bool ok = okr && q < nvalid;
+              const float t = src[ok ? q : 0];
+              val[j][u] = ok ? t : 0.f;
+            }
+          }
+#pragma unroll
+          for (int j = 0; j < RG; ++j) {
+            const int ml = wave + (jg + j) * NW;
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+              const int q = q0 + 64 * u;
+              if (q < DAP) Da[ml * DAP + q] = val[j][u];
+            }
+          }
+        }
+      }
     }
     // ---- stage input window: Bx[c_local][r] ----
-    for (int cl = wave; cl < CB; cl += NW) {
-      const int c = c0 + cl;
-      const bool ok = c < a.C;
-      const float* src = a.in + ((long)n * a.C + (ok ? c : 0)) * Psrc;
+    {
+      constexpr int RPW = CB / NW;        // 8, 16 or 32
+      constexpr int RG = 8;
       const int g0 = f0 * V;
-      for (int r = lane; r < WLP; r += 64) {
-        const int gp = g0 + r;
-        Bx[cl * WLP + r] = (ok && r < WL && gp >= 0 && gp < Psrc) ? src[gp] : 0.f;
+      for (int jg = 0; jg < RPW; jg += RG) {
+        for (int r0 = lane; r0 < WLP; r0 += 128) {
+          float val[RG][2];
+#pragma unroll
+          for (int j = 0; j < RG; ++j) {
+            const int cl = wave + (jg + j) * NW;
+            const int c = c0 + cl;
+            const bool okr = c < a.C;
+            const float* src = a.in + ((long)n * a.C + (okr ? c : 0)) * Psrc;
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+              const int r = r0 + 64 * u;
+              const int gp = g0 + r;
+              const bool ok = okr && r < WL && gp >= 0 && gp < Psrc;
+              const float t = src[ok ? gp : 0];
+              val[j][u] = ok ? t : 0.f;
+            }
+          }
+#pragma unroll
+          for (int j = 0; j < RG; ++j) {
+            const int cl = wave + (jg + j) * NW;
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+              const int r = r0 + 64 * u;
+              if (r < WLP) Bx[cl * WLP + r] = val[j][u];
+            }
+          }
+        }
       }
     }
     if (AGG && n != last_n) {

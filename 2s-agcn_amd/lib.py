@@ -37,8 +37,10 @@ SIGNATURES = {
     "agcn_gcn_project_bwd_weight": (_I, [_P, _P, _P, _P, _P, _Z, _I, _I, _I, _I, _I, _P]),
     "agcn_adjacency_fwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
     "agcn_adjacency_bwd_softmax": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
-    "agcn_adjacency_bwd_scores": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
-    "agcn_bn_stats_finalize": (_I, [_P, _I, _I, _D, _P, _P, _P, _P, _F, _F, _P, _P, _P, _P, _P]),
+    "agcn_adjacency_bwd_scores": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
+    "agcn_colsum_scratch_bytes": (_Z, [_I]),
+    "agcn_colsum": (_I, [_P, _I, _I, _P, _P, _P]),
+    "agcn_bn_stats_finalize": (_I, [_P, _I, _I, _D, _P, _P, _P, _P, _F, _F, _P, _P, _P, _P, _P, _P]),
     "agcn_bn_eval_coeff": (_I, [_P, _P, _P, _P, _F, _I, _P, _P, _P]),
     "agcn_bn_act_fwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
     "agcn_bn_bwd": (_I, [_P] * 18 + [_I, _I, _I, _P]),

@@ -22,6 +22,12 @@ def _empty(shape, like):
     return torch.empty(shape, dtype=torch.float32, device=like.device)
 
 
+def _scratch(width, like):
+    """Scratch for the two-stage column reductions (agcn_colsum_scratch_bytes)."""
+    nbytes = _L().agcn_colsum_scratch_bytes(int(width))
+    return torch.empty((nbytes + 7) // 8, dtype=torch.float64, device=like.device)
+
+
 # ------------------------------------------------------------------------------------------------
 # thin wrappers (one C entry point each)
 # ------------------------------------------------------------------------------------------------
@@ -139,8 +145,9 @@ def adjacency_bwd(dy, wcat, x, tp, P, alpha=None):
     dtp = _empty(tuple(tp.shape), x)
     dbpart = _empty((N * nt, 6 * Ci), x)
     dbab = _empty((6 * Ci,), x)
+    scratch = _scratch(6 * Ci, x)
     _lib.check(_L().agcn_adjacency_bwd_scores(_lib.ptr(tp), _lib.ptr(dS), _lib.ptr(dtp), _lib.ptr(dbpart),
-                                              _lib.ptr(dbab), N, Ci, T, V, _lib.stream()),
+                                              scratch.data_ptr(), _lib.ptr(dbab), N, Ci, T, V, _lib.stream()),
                "agcn_adjacency_bwd_scores")
     dalpha = dal_part.sum() if dal_part is not None else None
     return dPA, dtp, dbab, dalpha, dadj
@@ -157,9 +164,11 @@ def bn_train_coeffs(stats_part, count, gamma, beta, running_mean, running_var, m
     st.mean, st.invstd = _empty((C,), gamma), _empty((C,), gamma)
     st.scale, st.shift = _empty((C,), gamma), _empty((C,), gamma)
     nslots = stats_part.shape[0]
+    scratch = _scratch(2 * C, gamma)
     _lib.check(_L().agcn_bn_stats_finalize(_lib.ptr(stats_part), nslots, C, float(count), _lib.ptr(gamma),
                                            _lib.ptr(beta), _lib.ptr(running_mean), _lib.ptr(running_var),
-                                           float(momentum), float(eps), _lib.ptr(st.mean), _lib.ptr(st.invstd),
+                                           float(momentum), float(eps), scratch.data_ptr(), _lib.ptr(st.mean),
+                                           _lib.ptr(st.invstd),
                                            _lib.ptr(st.scale), _lib.ptr(st.shift), _lib.stream()),
                "agcn_bn_stats_finalize")
     return st

@@ -1,0 +1,196 @@
+"""Benchmark of the AGCN hot path: skeleton-clips/sec, forward+backward(+clip+SGD step), NTU (N,3,300,25,2).
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+
+One process per GPU; per-GPU batch fixed at 64 (BASELINE.json configs[1]/[2], weak scaling); gradients are summed by
+ONE RCCL all-reduce of the flat gradient buffer per step.  Rank 0 prints one JSON line.  Inputs are synthetic and
+resident in HBM before the timed region.  The roofline object is measured live (HIP events on the launch stream)
+for the dominant kernel; the cpu_baseline object times the CPU oracle (a port of the reference, never the product
+path) on a bounded sample on this box's host cores.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+PEAK_FP32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: exact-f32 matrix rate (v_mfma_f32_32x32x2_f32)
+
+
+def build_model(num_class=60, num_point=25, graph='graph.ntu_rgb_d.Graph'):
+    import agcn_amd  # noqa: F401
+    from model.agcn import Model
+    return Model(num_class=num_class, num_point=num_point, num_person=2, graph=graph,
+                 graph_args=dict(labeling_mode='spatial'))
+
+
+def randomize_like_training(model, seed):
+    """Random-init weights of the architecture, moved off the degenerate initialisation (bn weight 1e-6
+    and PA 1e-6 make the adaptive branch numerically invisible); timing does not depend on the values."""
+    g = torch.Generator().manual_seed(seed)
+    with torch.no_grad():
+        for name, p in model.named_parameters():
+            if name.endswith('gcn1.bn.weight'):
+                p.copy_(torch.rand(p.shape, generator=g) + 0.5)
+            elif name.endswith('.PA'):
+                p.copy_(0.05 * torch.randn(p.shape, generator=g))
+
+
+def dominant_kernel_roofline(device, reps=10):
+    """Time the dominant kernel of the step (unit_tcn 9x1 weight-gradient contraction at the l2-l4 shape,
+    N'=128, C=64, T=300, V=25) with HIP events on the stream it is launched on."""
+    import agcn_amd  # noqa: F401
+    from agcn_amd import ops
+    N, C, T, V = 128, 64, 300, 25
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(N, C, T, V, generator=g).to(device)
+    dy = torch.randn(N, C, T, V, generator=g).to(device)
+    w_shape = (C, C, 9, 1)
+    for _ in range(2):
+        ops.conv_bwd_weight(dy, x, w_shape)
+    torch.cuda.synchronize()
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    s.record()
+    for _ in range(reps):
+        ops.conv_bwd_weight(dy, x, w_shape)
+    e.record()
+    torch.cuda.synchronize()
+    ms = s.elapsed_time(e) / reps
+    flops = 2.0 * C * C * 9 * T * V * N          # algorithmic: 2*Cout*Cin*9 per output position
+    achieved = flops / (ms * 1e-3) / 1e12
+    return {"bound": "mfma", "kernel": "conv_wgrad_kernel<9,0,2,2,1,1> (unit_tcn dW, l2-l4 shape)",
+            "achieved": round(achieved, 2), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
+            "frac": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": None,
+            "ms_per_launch": round(ms, 4), "flops_per_launch": flops}
+
+
+def host_cores():
+    """CPU share of this process: the affinity mask, capped at the 16 cores a one-GPU box grants."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    return max(1, min(n, int(os.environ.get('AGCN_CPU_THREADS', '16'))))
+
+
+def cpu_baseline(batch=2, budget_s=20.0, max_steps=8):
+    """The CPU oracle (port of reference agcn.py, pinned to reference-generated fixtures) doing the same training step
+    on a bounded sample: training steps of `batch` clips for about `budget_s` seconds after one warm-up step."""
+    import numpy as np
+    from oracle import agcn_oracle as orc
+    from agcn_amd.graph.ntu_rgb_d import Graph
+    cores = host_cores()
+    torch.set_num_threads(cores)
+    A = torch.from_numpy(Graph().A.astype(np.float32))
+    sd = orc.with_grad(orc.randomized_state(orc.model_param_shapes(60, 25), 1, stress=1.0))
+    params = [v for k, v in sd.items() if not orc.is_buffer(k)]
+    opt = torch.optim.SGD(params, lr=0.1, momentum=0.9, nesterov=True, weight_decay=1e-4)
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(batch, 3, 300, 25, 2, generator=g)
+    y = torch.randint(0, 60, (batch,), generator=g)
+
+    def step():
+        loss = torch.nn.functional.cross_entropy(orc.model_forward(x, sd, A, training=True), y)
+        opt.zero_grad()
+        loss.backward()
+        torch.nn.utils.clip_grad_norm_(params, 1.0)
+        opt.step()
+    print(f"[bench] cpu_baseline: warm-up step on {cores} threads ...", file=sys.stderr, flush=True)
+    step()
+    t0 = time.perf_counter()
+    steps = 0
+    while steps < max_steps and (time.perf_counter() - t0) < budget_s:
+        step()
+        steps += 1
+        print(f"[bench] cpu_baseline: step {steps} at {time.perf_counter() - t0:.1f}s", file=sys.stderr, flush=True)
+    dt = time.perf_counter() - t0
+    return {"value": round(batch * steps / dt, 3), "unit": "clips/s", "cores": cores, "kind": "port",
+            "sample": f"{steps} training steps of batch {batch} (fwd+bwd+clip+SGD) after 1 warm-up, fp32, "
+                      f"torch {torch.__version__} CPU ops, {cores} threads"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=20)
+    ap.add_argument('--warmup', type=int, default=5)
+    ap.add_argument('--batch', type=int, default=64, help='per-GPU batch (BASELINE configs[1]: 64)')
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-roofline', action='store_true')
+    args = ap.parse_args()
+
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    if args.gpus > 1 and world == 1:
+        raise SystemExit("bench.py --gpus N>1 must be launched with torch.distributed.run (one process per GPU)")
+    torch.cuda.set_device(local_rank)
+    device = torch.device('cuda', local_rank)
+    if world > 1:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group(backend='nccl', device_id=device)
+
+    import agcn_amd  # noqa: F401
+    from agcn_amd.trainer import TrainEngine, synthetic_batch
+    torch.manual_seed(0)                       # identical initial weights on every rank
+    model = build_model()
+    randomize_like_training(model, seed=0)
+    model.to(device)
+    engine = TrainEngine(model, base_lr=0.1, momentum=0.9, nesterov=True, weight_decay=1e-4, max_grad_norm=1.0,
+                         world_size=world)
+    data, label = synthetic_batch(args.batch, seed=1234 + rank, device=device)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        engine.train_step(data, label)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = engine.train_step(data, label)
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([dt], dtype=torch.float64, device=device)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+    final_loss = float(loss.detach())
+    if rank == 0:
+        print(f"[bench] timed {args.steps} steps in {dt:.3f}s", file=sys.stderr, flush=True)
+
+    if rank == 0:
+        clips = args.batch * world * args.steps
+        out = {
+            "metric": "skeleton-clips/sec fwd+bwd, NTU (N,3,300,25,2)",
+            "value": round(clips / dt, 2), "unit": "clips/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "AGCN joint-stream NTU-xview shape, full training step "
+                                   "(fwd, CE, bwd, grad all-reduce, clip 1.0, SGD nesterov)",
+                       "per_gpu_batch": args.batch, "global_batch": args.batch * world, "input": "(N,3,300,25,2)",
+                       "parallelism": f"dp{world}", "bn": "per-replica"},
+            "final_loss": round(final_loss, 5),
+        }
+        if world == 1 and not args.no_roofline:
+            out["roofline"] = dominant_kernel_roofline(device)
+            print("[bench] roofline done", file=sys.stderr, flush=True)
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

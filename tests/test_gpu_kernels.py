@@ -180,8 +180,9 @@ def test_adjacency_fwd_bwd(case):
     dtp = torch.empty_like(tpg)
     dbpart = torch.empty((N * nt, 6 * Ci), device=dev)
     db = torch.empty((6 * Ci,), device=dev)
-    lib.check(L.agcn_adjacency_bwd_scores(lib.ptr(tpg), lib.ptr(dS), lib.ptr(dtp), lib.ptr(dbpart), lib.ptr(db), N,
-                                          Ci, T, V, lib.stream()), 'bwd_scores')
+    scratch = ops._scratch(6 * Ci, tpg)
+    lib.check(L.agcn_adjacency_bwd_scores(lib.ptr(tpg), lib.ptr(dS), lib.ptr(dtp), lib.ptr(dbpart),
+                                          scratch.data_ptr(), lib.ptr(db), N, Ci, T, V, lib.stream()), 'bwd_scores')
     gmax = max(1e-30, float(tp.grad.abs().max()))
     assert float((dtp.double().cpu() - tp.grad).abs().max()) / gmax < 2e-4
     db_ref = tp.grad.sum((0, 2, 3))
