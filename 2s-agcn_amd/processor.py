@@ -1,0 +1,281 @@
+"""``Processor``: counterpart of the reference training runtime for THIS hot path only
+(reference utils/processor.py: load_model :286-343, adjust_learning_rate :349-360, train :604-778, eval :784-914,
+save/load_weights :225-270) and of its config surface (utils/parser.py:9-282).
+
+What is kept: the flag names and yaml keys of the AGCN configs (``model``, ``model_args``, ``base_lr``, ``step``,
+``weight_decay``, ``nesterov``, ``batch_size``, ``test_batch_size``, ``num_epoch``, ``warm_up_epoch``, ``device``,
+``weights``, ``ignore_weights``, ``work_dir`` ...), precedence defaults < config file < command line, dotted class
+paths resolved by ``import_class``, state_dict checkpoints named ``<work_dir>/weight/<model>-<epoch>-<step>.pt``,
+per-epoch LR rule, mean-CE loss, clip 1.0, SGD.  What differs (MI355X-first): one process per GPU, flat
+parameter/gradient buffers, one RCCL all-reduce and one fused clip+SGD launch chain per step (trainer.py), tensor
+or tuple model outputs both accepted, unknown config keys warn instead of assert, and a
+built-in synthetic feeder so the loop runs without a dataset.  Out of scope here: SAM/Adam/LLRD optimizers,
+TensorBoard, the SGN feeders.
+"""
+import argparse
+import importlib
+import os
+import pickle
+import time
+
+import numpy as np
+import torch
+import yaml
+
+from . import dp as _dp
+from .trainer import TrainEngine, learning_rate
+
+
+def import_class(name):
+    module_name, _, cls = name.rpartition('.')
+    return getattr(importlib.import_module(module_name), cls)
+
+
+def str2bool(v):
+    return str(v).lower() in ('yes', 'true', 't', 'y', '1')
+
+
+def get_parser():
+    p = argparse.ArgumentParser(description='2s-AGCN on MI355X')
+    p.add_argument('--work-dir', default='./work_dir/temp')
+    p.add_argument('--config', default=None)
+    p.add_argument('--phase', default='train')
+    p.add_argument('--seed', type=int, default=1)
+    p.add_argument('--log-interval', type=int, default=100)
+    p.add_argument('--save-interval', type=int, default=2)
+    p.add_argument('--eval-interval', type=int, default=5)
+    p.add_argument('--print-log', type=str2bool, default=True)
+    p.add_argument('--show-topk', type=int, default=[1, 5], nargs='+')
+    p.add_argument('--feeder', default='agcn_amd.processor.SyntheticFeeder')
+    p.add_argument('--num-worker', type=int, default=0)
+    p.add_argument('--train-feeder-args', default=dict())
+    p.add_argument('--test-feeder-args', default=dict())
+    p.add_argument('--model', default='model.agcn.Model')
+    p.add_argument('--model-args', default=dict())
+    p.add_argument('--model-saved-name', default='')
+    p.add_argument('--weights', default=None)
+    p.add_argument('--ignore-weights', type=str, default=[], nargs='+')
+    p.add_argument('--base-lr', type=float, default=0.1)
+    p.add_argument('--step', type=int, default=[30, 40], nargs='+')
+    p.add_argument('--device', type=int, default=0, nargs='+')
+    p.add_argument('--optimizer', default='SGD')
+    p.add_argument('--nesterov', type=str2bool, default=True)
+    p.add_argument('--batch-size', type=int, default=64)
+    p.add_argument('--test-batch-size', type=int, default=64)
+    p.add_argument('--start-epoch', type=int, default=0)
+    p.add_argument('--num-epoch', type=int, default=50)
+    p.add_argument('--weight-decay', type=float, default=1e-4)
+    p.add_argument('--warm-up-epoch', type=int, default=0)
+    p.add_argument('--only-train-part', type=str2bool, default=False)
+    p.add_argument('--only-train-epoch', type=int, default=0)
+    p.add_argument('--ddp', type=str2bool, default=False)
+    p.add_argument('--world-size', type=int, default=1)
+    p.add_argument('--max-steps-per-epoch', type=int, default=0, help='0 = whole epoch (synthetic smoke runs)')
+    return p
+
+
+def load_args(argv=None):
+    """defaults < yaml config < command line (reference utils/parser.py:248-282); unknown config keys only warn."""
+    parser = get_parser()
+    pre, _ = parser.parse_known_args(argv)
+    if pre.config is not None:
+        with open(pre.config, 'r') as f:
+            cfg = yaml.safe_load(f) or {}
+        known = vars(pre).keys()
+        unknown = [k for k in cfg if k not in known]
+        if unknown:
+            print(f'[agcn_amd] ignoring config keys outside the AGCN hot path: {unknown}')
+        parser.set_defaults(**{k: v for k, v in cfg.items() if k in known})
+    return parser.parse_args(argv)
+
+
+class SyntheticFeeder(torch.utils.data.Dataset):
+    """Stand-in for the reference Feeder (feeders/feeder.py:35-227) when no dataset is present: seeded N(0,1) clips of
+    shape (3, T, V, M) with uniform labels; __getitem__ returns (data, label, index) like the reference."""
+
+    def __init__(self, num_samples=256, num_point=25, num_class=60, window_size=300, num_person=2, seed=0, **_):
+        g = np.random.default_rng(seed)
+        self.data = g.standard_normal((num_samples, 3, window_size, num_point, num_person)).astype(np.float32)
+        self.label = g.integers(0, num_class, size=(num_samples,)).astype(np.int64)
+
+    def __len__(self):
+        return len(self.label)
+
+    def __getitem__(self, i):
+        return self.data[i], self.label[i], i
+
+
+class NpyFeeder(torch.utils.data.Dataset):
+    """Reads the reference's on-disk format (data_gen/ntu_gendata.py:158-173): ``data_path`` .npy (N,3,T,V,M) fp32
+    (memory-mapped) and ``label_path`` .pkl (names, labels) or .npy labels."""
+
+    def __init__(self, data_path, label_path, **_):
+        self.data = np.load(data_path, mmap_mode='r')
+        if label_path.endswith('.npy'):
+            self.label = np.load(label_path).astype(np.int64)
+        else:
+            with open(label_path, 'rb') as f:      # the user's own dataset file, as in the reference feeder
+                _, labels = pickle.load(f, encoding='latin1')
+            self.label = np.asarray(labels, dtype=np.int64)
+
+    def __len__(self):
+        return len(self.label)
+
+    def __getitem__(self, i):
+        return np.asarray(self.data[i], dtype=np.float32), self.label[i], i
+
+
+class Processor:
+    def __init__(self, arg):
+        self.arg = arg
+        self.rank, self.world = _dp.init_distributed()
+        dev = arg.device if isinstance(arg.device, int) else arg.device[0]
+        local = int(os.environ.get('LOCAL_RANK', dev))
+        torch.cuda.set_device(local)
+        self.device = torch.device('cuda', local)
+        torch.manual_seed(arg.seed)
+        np.random.seed(arg.seed)
+        os.makedirs(os.path.join(arg.work_dir, 'weight'), exist_ok=True)
+        self.global_step = 0
+        self.load_model()
+        self.load_data()
+        self.engine = TrainEngine(self.model, base_lr=arg.base_lr, momentum=0.9, nesterov=arg.nesterov,
+                                  weight_decay=arg.weight_decay, max_grad_norm=1.0, world_size=self.world)
+        _dp.broadcast_parameters(self.engine.fp.flat, self.world)
+        self.best_acc = 0.0
+
+    # ---- logging --------------------------------------------------------------------------------------------------
+    def print_log(self, msg):
+        if self.rank == 0:
+            line = f"[ {time.strftime('%a %b %d %H:%M:%S %Y')} ] {msg}"
+            print(line, flush=True)
+            if self.arg.print_log:
+                with open(os.path.join(self.arg.work_dir, 'log.txt'), 'a') as f:
+                    print(line, file=f)
+
+    # ---- model / weights -----------------------------------------------------------------------------------------
+    def load_model(self):
+        Model = import_class(self.arg.model)
+        self.model = Model(**self.arg.model_args).to(self.device)
+        if self.arg.weights:
+            self.load_weights(self.arg.weights)
+
+    def load_weights(self, path):
+        name = os.path.basename(path)
+        try:
+            self.global_step = int(name[:-3].split('-')[-1])     # <model>-<epoch>-<global_step>.pt
+        except ValueError:
+            self.global_step = 0
+        weights = torch.load(path, map_location='cpu', weights_only=True)
+        weights = {k.replace('module.', '', 1) if k.startswith('module.') else k: v for k, v in weights.items()}
+        for key in self.arg.ignore_weights:
+            for k in [k for k in weights if key in k]:
+                weights.pop(k)
+                self.print_log(f'Successfully removed weights: {k}')
+        state = self.model.state_dict()
+        missing = set(state) - set(weights)
+        if missing:
+            self.print_log(f'Cannot find these weights (kept at init): {sorted(missing)}')
+        state.update({k: v for k, v in weights.items() if k in state})
+        self.model.load_state_dict(state)
+
+    def save_weights(self, epoch):
+        if self.rank != 0:
+            return None
+        sd = {k: v.detach().cpu().clone() for k, v in self.model.state_dict().items()}
+        name = self.arg.model_saved_name or os.path.join(self.arg.work_dir, 'weight', 'agcn')
+        path = f'{name}-{epoch}-{int(self.global_step)}.pt'
+        os.makedirs(os.path.dirname(path) or '.', exist_ok=True)
+        torch.save(sd, path)
+        return path
+
+    # ---- data -----------------------------------------------------------------------------------------------------
+    def load_data(self):
+        Feeder = import_class(self.arg.feeder)
+        self.data_loader = {}
+        if self.arg.phase == 'train':
+            ds = Feeder(**self.arg.train_feeder_args)
+            idx = _dp.shard_indices(len(ds), self.rank, self.world)
+            self.data_loader['train'] = torch.utils.data.DataLoader(
+                torch.utils.data.Subset(ds, idx), batch_size=self.arg.batch_size, shuffle=True, drop_last=True,
+                num_workers=self.arg.num_worker, pin_memory=True)
+        ds = Feeder(**(self.arg.test_feeder_args or self.arg.train_feeder_args))
+        idx = _dp.shard_indices(len(ds), self.rank, self.world)
+        self.data_loader['test'] = torch.utils.data.DataLoader(
+            torch.utils.data.Subset(ds, idx), batch_size=self.arg.test_batch_size, shuffle=False, drop_last=False,
+            num_workers=self.arg.num_worker, pin_memory=True)
+
+    # ---- one epoch ------------------------------------------------------------------------------------------------
+    def train(self, epoch):
+        self.engine.lr = learning_rate(epoch, self.arg.base_lr, self.arg.step, self.arg.warm_up_epoch)
+        freeze_pa = self.arg.only_train_part and epoch <= self.arg.only_train_epoch
+        self.print_log(f'Training epoch: {epoch + 1}, lr {self.engine.lr:.6f}')
+        t_data = t_net = 0.0
+        losses, t0 = [], time.perf_counter()
+        for step, (data, label, _) in enumerate(self.data_loader['train']):
+            data = data.to(self.device, non_blocking=True)
+            label = label.to(self.device, non_blocking=True)
+            t1 = time.perf_counter()
+            t_data += t1 - t0
+            # reference zeroes the PA gradients while epoch <= only_train_epoch (processor.py:699-702); here they are
+            # zeroed before the fused clip+update, so the clip norm excludes them (the reference clips first)
+            loss = self.engine.train_step(data, label, before_step=self._zero_pa_grads if freeze_pa else None)
+            self.global_step += 1
+            if step % self.arg.log_interval == 0:
+                losses.append(float(loss.detach()))
+                self.print_log(f'\tBatch({step}/{len(self.data_loader["train"])}) done. Loss: {losses[-1]:.4f}  '
+                               f'lr:{self.engine.lr:.6f}  grad-norm:{self.engine.grad_norm():.3f}')
+            t0 = time.perf_counter()
+            t_net += t0 - t1
+            if self.arg.max_steps_per_epoch and step + 1 >= self.arg.max_steps_per_epoch:
+                break
+        torch.cuda.synchronize()
+        tot = max(t_data + t_net, 1e-9)
+        self.print_log(f'\tMean training loss: {np.mean(losses) if losses else float("nan"):.4f}.  '
+                       f'Time consumption: [Data]{100 * t_data / tot:.0f}%, [Network]{100 * t_net / tot:.0f}%')
+
+    def _zero_pa_grads(self):
+        for n, p in self.model.named_parameters():
+            if 'PA' in n and p.grad is not None:
+                p.grad.zero_()
+
+    def eval(self, epoch):
+        self.model.eval()
+        scores, labels, loss_sum, n = [], [], 0.0, 0
+        with torch.no_grad():
+            for data, label, _ in self.data_loader['test']:
+                data = data.to(self.device, non_blocking=True)
+                label = label.to(self.device, non_blocking=True)
+                out = self.model(data)
+                out = out[0] if isinstance(out, tuple) else out
+                loss_sum += float(torch.nn.functional.cross_entropy(out, label, reduction='sum'))
+                n += label.numel()
+                scores.append(out.cpu())
+                labels.append(label.cpu())
+        score, label = torch.cat(scores), torch.cat(labels)
+        res = {}
+        for k in self.arg.show_topk:
+            hit = (score.topk(min(k, score.shape[1]), dim=1).indices == label[:, None]).any(1).double().sum().item()
+            res[k] = _dp.allreduce_scalar(hit, self.world, self.device)
+        total = _dp.allreduce_scalar(n, self.world, self.device)
+        loss = _dp.allreduce_scalar(loss_sum, self.world, self.device) / max(total, 1)
+        self.print_log(f'\tMean test loss of {int(total)} samples: {loss:.4f}')
+        for k, hit in res.items():
+            self.print_log(f'\tTop{k}: {100.0 * hit / max(total, 1):.2f}%')
+        self.best_acc = max(self.best_acc, res.get(1, 0.0) / max(total, 1))
+        return loss, {k: v / max(total, 1) for k, v in res.items()}
+
+    def start(self):
+        if self.arg.phase == 'train':
+            self.print_log(f'Parameters: {sum(p.numel() for p in self.model.parameters())}, world {self.world}')
+            for epoch in range(self.arg.start_epoch, self.arg.num_epoch):
+                self.train(epoch)
+                if (epoch + 1) % self.arg.save_interval == 0 or epoch + 1 == self.arg.num_epoch:
+                    self.save_weights(epoch + 1)
+                if (epoch + 1) % self.arg.eval_interval == 0 or epoch + 1 == self.arg.num_epoch:
+                    self.eval(epoch)
+            self.print_log(f'best accuracy: {self.best_acc}')
+        else:
+            if self.arg.weights is None:
+                raise ValueError('Please appoint --weights.')
+            self.eval(0)

@@ -14,8 +14,7 @@ MI355X-first differences from the reference's DDP path:
 """
 import numpy as np
 import torch
-import torch.distributed as dist
-
+from . import dp as _dp
 from . import lib as _lib
 
 
@@ -73,8 +72,9 @@ class TrainEngine:
         self.norm = torch.zeros(2, dtype=torch.float32, device=dev)
         self.loss_fn = torch.nn.CrossEntropyLoss()
 
-    def train_step(self, data, label):
-        """One optimisation step on a device-resident batch.  Returns the (device) loss tensor."""
+    def train_step(self, data, label, before_step=None):
+        """One optimisation step on a device-resident batch.  Returns the (device) loss tensor.
+        ``before_step`` (optional) runs after the gradient all-reduce and before the fused clip+SGD update."""
         self.model.train()
         output = self.model(data)
         if isinstance(output, tuple):
@@ -82,8 +82,9 @@ class TrainEngine:
         loss = self.loss_fn(output, label)
         self.fp.zero_grad()
         loss.backward()
-        if self.world_size > 1:
-            dist.all_reduce(self.fp.grad, op=dist.ReduceOp.SUM)     # RCCL over xGMI; averaged inside the update
+        _dp.allreduce_gradients(self.fp.grad, self.world_size)     # RCCL over xGMI; averaged inside the update
+        if before_step is not None:
+            before_step()
         L = _lib.load()
         _lib.check(L.agcn_sgd_step(self.fp.flat.data_ptr(), self.fp.grad.data_ptr(), self.fp.momentum.data_ptr(),
                                    self.fp.total, float(self.lr), float(self.momentum), float(self.weight_decay),

@@ -1,0 +1,128 @@
+/* agcn_hip.h -- C ABI of libagcn_hip.so: the 2s-AGCN hot path (unit_gcn / unit_tcn / TCN_GCN_unit forward and
+ * backward, and the clip+SGD tail of the training step) as hand-written gfx950 (MI355X, CDNA4) HIP kernels.
+ *
+ * The reference (cheneeheng/2s-AGCN) is pure Python/PyTorch and has no FFI for this path; every entry point below
+ * replaces the stock ATen operators that one line range of the reference launches (cited per function as
+ * agcn.py:<lines> = model/architecture/aagcn/agcn.py, processor.py = utils/processor.py).  INTEGRATION.md shows the
+ * ctypes binding a maintainer of the reference would add.
+ *
+ * Conventions
+ *  - every pointer is a DEVICE pointer to contiguous fp32 owned by the caller (PyTorch's caching allocator in our
+ *    host code); the library never allocates, frees or keeps device memory; scratch/workspace is passed in and its
+ *    size is given by the matching *_workspace / *_scratch_bytes / *_num_* query;
+ *  - activations are (N, C, T, V) row-major ("NCHW"), N = batch*persons, V <= 32 joints, P = T*V;
+ *  - `stream` is a hipStream_t passed as void*; all work is enqueued on it, nothing synchronises the device, the
+ *    functions are re-entrant and hold no mutable global state (forward and autograd-backward threads may call
+ *    concurrently);
+ *  - return value: 0 = ok, AGCN_ERR_* (negative) = argument/shape problem detected on the host before any launch,
+ *    positive = hipError_t of a failed launch.  Nothing throws or aborts.
+ *  - results are bitwise reproducible run to run (no float atomics; all cross-workgroup sums go through slabs that
+ *    are added in a fixed order).
+ */
+#ifndef AGCN_HIP_H
+#define AGCN_HIP_H
+
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define AGCN_OK 0
+#define AGCN_ERR_ARG (-1)         /* null pointer / non-positive size / V > 32 */
+#define AGCN_ERR_WORKSPACE (-2)   /* workspace smaller than the query says */
+#define AGCN_ERR_UNSUPPORTED (-3) /* taps not in {1,9}, stride not in {1,2}, element count not a multiple of 4 ... */
+
+/* load-time checks */
+int agcn_version(void);          /* 100 = 0.1.0 */
+const char* agcn_arch(void);     /* "gfx950" */
+
+/* ---- tile geometry queries (sizes of the partial slabs below) ---------------------------------------------------- */
+int agcn_conv_tile_frames(int V, int T_out);     /* frames per position tile of the contraction kernels (256/V) */
+int agcn_conv_num_tiles(int V, int T_out);       /* tiles per sample -> stats_part has N*num_tiles slots */
+int agcn_scores_num_tiles(int V, int T);         /* tiles per sample of the adjacency-score kernels */
+int agcn_dadj_num_slots(int C, int V, int T);    /* slots per (sample, subset) of the adjacency-gradient slab */
+
+/* ---- channel contractions: unit_tcn's Conv2d((k,1), stride (s,1), pad ((k-1)/2,0)) and every 1x1 Conv2d ------------
+ * replaces: nn.Conv2d forward/backward at agcn.py:40-41,49 (unit_tcn.conv), :66-68,99-100 (conv_a/conv_b),
+ *           :73 (down conv), and the kernel_size=1 residual unit_tcn at :125.   taps in {1,9}, stride in {1,2}.
+ * w: (Cout, Cin, taps, 1) as in the reference state_dict.  stats_part (optional, may be NULL): per-channel partial
+ * (sum, sum of squares) of y, layout [N*agcn_conv_num_tiles][2][Cout], consumed by agcn_bn_stats_finalize. */
+int agcn_conv_fwd(const float* x, const float* w, const float* bias, float* y, float* stats_part, int N, int Cin,
+                  int Cout, int T, int V, int taps, int stride, void* stream);
+/* dx (+)= conv^T(dy) [+ add1*(mask1>0)] [+ add2*(mask2>0)]; add/mask are dx-shaped or NULL (mask NULL = no masking);
+ * they fold the ReLU-masked identity-residual gradients (agcn.py:108-109,128-129) into the epilogue. */
+int agcn_conv_bwd_data(const float* dy, const float* w, float* dx, int accumulate, const float* add1,
+                       const float* mask1, const float* add2, const float* mask2, int N, int Cin, int Cout, int T,
+                       int V, int taps, int stride, void* stream);
+size_t agcn_conv_bwd_weight_workspace(int N, int Cin, int Cout, int T, int V, int taps, int stride);
+int agcn_conv_bwd_weight(const float* dy, const float* x, float* dw, void* workspace, size_t workspace_bytes, int N,
+                         int Cin, int Cout, int T, int V, int taps, int stride, void* stream);
+
+/* ---- unit_gcn: graph aggregation fused with the conv_d projection --------------------------------------------------
+ * replaces agcn.py:103-105:  y = sum_i conv_d[i]( matmul(x.view(N,C*T,V), A^_i) )   (three bmm + three 1x1 convs + adds)
+ * adj: (N,3,V,V) = A^ from agcn_adjacency_fwd ; wcat: (Cout, 3*C) = [Wd_0 | Wd_1 | Wd_2] ; bias: sum of the three
+ * conv_d biases (or NULL). */
+int agcn_gcn_aggregate_project_fwd(const float* x, const float* adj, const float* wcat, const float* bias, float* y,
+                                   float* stats_part, int N, int C, int Cout, int T, int V, void* stream);
+int agcn_gcn_aggregate_project_bwd_data(const float* dy, const float* adj, const float* wcat, float* dx,
+                                        int accumulate, const float* add1, const float* mask1, const float* add2,
+                                        const float* mask2, int N, int C, int Cout, int T, int V, void* stream);
+size_t agcn_gcn_project_bwd_weight_workspace(int N, int C, int Cout, int T, int V);
+int agcn_gcn_project_bwd_weight(const float* dy, const float* x, const float* adj, float* dwcat, void* workspace,
+                                size_t workspace_bytes, int N, int C, int Cout, int T, int V, void* stream);
+/* dadj_part: (N, 3, agcn_dadj_num_slots, V, V) partial adjacency gradients, summed by agcn_adjacency_bwd_softmax */
+int agcn_gcn_dadj(const float* dy, const float* wcat, const float* x, float* dadj_part, int N, int C, int Cout,
+                  int T, int V, void* stream);
+
+/* ---- adaptive adjacency ------------------------------------------------------------------------------------------------
+ * replaces agcn.py:95,99-102:  A^_i = softmax_{dim -2}( theta_i^T phi_i / (Ci*T) ) + A_i + PA_i
+ * tp: (N, 6*Ci, T, V), rows [theta_0|phi_0|theta_1|phi_1|theta_2|phi_2] (one agcn_conv_fwd with the six 1x1 weights
+ * stacked).  A: (3,V,V) constant graph (NULL for the AAGCN form), PA: (3,V,V) parameter, alpha: 1 float or NULL
+ * (AAGCN: A^ = PA + alpha*P, aagcn.py:172-173).  spart: scratch (N,3,agcn_scores_num_tiles,V,V).
+ * Outputs P (softmax, kept for the backward) and adj, both (N,3,V,V). */
+int agcn_adjacency_fwd(const float* tp, const float* A, const float* PA, const float* alpha, float* spart, float* P,
+                       float* adj, int N, int Ci, int T, int V, void* stream);
+/* dadj = sum of slots; dS = alpha*P*(dadj - sum_u P*dadj)/(Ci*T); dPA = sum_n dadj; dalpha_part (N*3) or NULL */
+int agcn_adjacency_bwd_softmax(const float* dadj_part, const float* P, const float* alpha, float* dadj, float* dS,
+                               float* dPA, float* dalpha_part, int N, int Ci, int T, int V, int nslots, void* stream);
+/* dtp from dS; db (6*Ci) = bias gradients of the stacked conv_a/conv_b; dbpart: scratch (N*tiles, 6*Ci);
+ * scratch: agcn_colsum_scratch_bytes(6*Ci) bytes */
+int agcn_adjacency_bwd_scores(const float* tp, const float* dS, float* dtp, float* dbpart, void* scratch, float* db,
+                              int N, int Ci, int T, int V, void* stream);
+
+/* ---- BatchNorm2d (train/eval) + residual + ReLU ---------------------------------------------------------------------
+ * replaces agcn.py:43,49 (unit_tcn.bn), :74 (down BN), :79,107-109 (unit_gcn.bn, += down(x), relu), :128-129
+ * (TCN_GCN_unit: + residual, relu).  eps 1e-5, momentum 0.1, biased variance for normalisation, unbiased for
+ * running_var -- the nn.BatchNorm2d defaults the reference uses. */
+size_t agcn_colsum_scratch_bytes(int W);
+int agcn_colsum(const float* X, int nslots, int W, void* scratch, float* out, void* stream);
+int agcn_bn_stats_finalize(const float* stats_part, int nslots, int C, double count, const float* gamma,
+                           const float* beta, float* running_mean, float* running_var, float momentum, float eps,
+                           void* scratch /* agcn_colsum_scratch_bytes(2*C) */, float* mean, float* invstd,
+                           float* scale, float* shift, void* stream);
+int agcn_bn_eval_coeff(const float* gamma, const float* beta, const float* running_mean, const float* running_var,
+                       float eps, int C, float* scale, float* shift, void* stream);
+/* out = act(scale1[c]*y1 + shift1[c] + res); res_mode 0: none, 1: r, 2: scale2[c]*r + shift2[c]; N*C*P % 4 == 0 */
+int agcn_bn_act_fwd(const float* y1, const float* scale1, const float* shift1, const float* r, const float* scale2,
+                    const float* shift2, float* out, int N, int C, int P, int res_mode, int relu, void* stream);
+/* train-mode backward of out = relu(bn1(y1) [+ bn2(y2)] [+ identity]); mask = out (NULL: no ReLU);
+ * part: scratch N*C*3 floats, coef: scratch 6*C floats */
+int agcn_bn_bwd(const float* dout, const float* mask, const float* y1, const float* gamma1, const float* mean1,
+                const float* invstd1, const float* y2, const float* gamma2, const float* mean2, const float* invstd2,
+                float* part, float* coef, float* dy1, float* dgamma1, float* dbeta1, float* dy2, float* dgamma2,
+                float* dbeta2, int N, int C, int P, void* stream);
+
+/* ---- training-step tail on one flat parameter buffer ----------------------------------------------------------------
+ * replaces processor.py:698 (clip_grad_norm_(params, 1.0)) + :703 (optimizer.step() of optim.SGD(momentum, nesterov,
+ * weight_decay), :395-401).  grad_scale multiplies the gradient first (1/world_size after a SUM all-reduce).
+ * norm_out: 2 device floats {global grad norm, clip coefficient}.  max_norm <= 0 disables clipping. */
+size_t agcn_sgd_step_workspace(long n);
+int agcn_sgd_step(float* param, const float* grad, float* momentum_buf, long n, float lr, float momentum,
+                  float weight_decay, int nesterov, float max_norm, float grad_scale, int first_step, void* workspace,
+                  size_t workspace_bytes, float* norm_out, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* AGCN_HIP_H */

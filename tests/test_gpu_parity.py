@@ -205,6 +205,68 @@ def test_unit_vs_oracle_seeded_batch():
         assert err32 < GTOL or err64 < GTOL + 3 * noise, (k, err32, err64, noise)
 
 
+def test_training_trace_three_steps():
+    """3 optimisation steps (fwd, CE, bwd, clip 1.0, SGD nesterov wd 1e-4, lr 0.1) vs the trace the REFERENCE produced
+    with torch.optim.SGD + clip_grad_norm_ (tests/golden/train_trace_ntu_b2.npz).  The loss of step k+1 depends on the
+    ReLU-kink-conditioned gradients of step k (see golden_util.grad_check), so losses are compared at 2e-3."""
+    dev = _gpu()
+    from agcn_amd.trainer import TrainEngine
+    from model.agcn import Model
+    gold = gu.load('train_trace_ntu_b2')
+    n, v, num_class, seed = [int(i) for i in gold['meta']]
+    model = Model(num_class=num_class, num_point=v, num_person=2, graph='graph.ntu_rgb_d.Graph',
+                  graph_args=dict(labeling_mode='spatial'))
+    model.load_state_dict(orc.randomized_state(orc.model_param_shapes(num_class, v), seed, stress=3.0))
+    model.to(dev)
+    eng = TrainEngine(model, base_lr=0.1, momentum=0.9, nesterov=True, weight_decay=1e-4, max_grad_norm=1.0)
+    losses, norms = [], []
+    for step in range(3):
+        xn, lab = gu.model_inputs(n, v, num_class, seed + step, 300)
+        loss = eng.train_step(torch.from_numpy(xn).to(dev), torch.from_numpy(lab).to(dev))
+        losses.append(float(loss.detach()))
+        norms.append(eng.grad_norm())
+    assert abs(losses[0] - gold['losses'][0]) < 1e-4 * abs(gold['losses'][0])
+    assert abs(norms[0] - gold['grad_norms'][0]) < 2e-3 * gold['grad_norms'][0]
+    for a, b in zip(losses[1:], gold['losses'][1:]):
+        assert abs(a - b) < 2e-3 * abs(b), (losses, gold['losses'])
+    sd = model.state_dict()
+    for k in ('fc.weight', 'l1.gcn1.PA', 'l5.tcn1.conv.weight', 'l10.gcn1.conv_d.2.weight'):
+        t = sd[k].double().cpu().numpy()
+        ref_norm = float(gold['final.' + k + '.norm'])
+        assert abs(np.linalg.norm(t) - ref_norm) < 1e-3 * ref_norm, k
+        idx = gold['final.' + k + '.idx']
+        ref = gold['final.' + k + '.samples'].astype(np.float64)
+        assert np.abs(t.reshape(-1)[idx] - ref).max() < 2e-3 * max(1e-12, np.abs(ref).max()), k
+
+
+def test_processor_smoke(tmp_path):
+    """The Processor counterpart end to end on synthetic clips: 2 steps of training, checkpoint, reload, eval."""
+    _gpu()
+    import os
+    from agcn_amd.processor import Processor, load_args
+    cfg = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'config', 'nturgbd-cross-view',
+                       'train_joint.yaml')
+    argv = ['--config', cfg, '--work-dir', str(tmp_path), '--model-saved-name', str(tmp_path / 'weight' / 'm'),
+            '--batch-size', '4', '--test-batch-size', '4', '--num-epoch', '1', '--max-steps-per-epoch', '2',
+            '--log-interval', '1', '--print-log', 'False']
+    arg = load_args(argv)
+    arg.train_feeder_args = dict(num_samples=8, window_size=64)
+    arg.test_feeder_args = dict(num_samples=8, window_size=64, seed=1)
+    p = Processor(arg)
+    p.start()
+    ckpts = os.listdir(tmp_path / 'weight')
+    assert ckpts and ckpts[0].endswith('-1-2.pt')
+    arg2 = load_args(argv + ['--phase', 'test', '--weights', str(tmp_path / 'weight' / ckpts[0])])
+    arg2.train_feeder_args = arg.train_feeder_args
+    arg2.test_feeder_args = arg.test_feeder_args
+    p2 = Processor(arg2)
+    assert p2.global_step == 2
+    for k, v_ in p.model.state_dict().items():
+        assert torch.equal(v_.cpu(), p2.model.state_dict()[k].cpu()), k
+    loss, acc = p2.eval(0)
+    assert np.isfinite(loss) and 0.0 <= acc[1] <= 1.0
+
+
 def test_cpu_input_raises():
     _gpu()
     from agcn_amd.model.agcn import TCN_GCN_unit
