@@ -1,7 +1,8 @@
 // Implicit-GEMM channel contraction on NCHW skeleton tensors, exact fp32 on the CDNA4 matrix cores
 // (v_mfma_f32_32x32x2_f32).  One kernel template covers
 //   * unit_tcn's (9x1)/(1x1) temporal convolution forward           (reference agcn.py:40-41,49)
-//   * its backward-data (transposed, tap-flipped; stride 1 and 2)
+//   * its backward-data (transposed, tap-flipped; stride 2 split by output-frame parity into a 5-tap and a
+//     4-tap stride-1 problem so no matrix-core work is spent on structural zeros)
 //   * every 1x1 conv of unit_gcn (conv_a/conv_b/down)               (reference agcn.py:66-75,99-100)
 //   * unit_gcn's fused aggregate+project  y = sum_i Wd_i (x . A^_i)  (reference agcn.py:103-105)
 //     and its backward-data  dx = sum_i Wd_i^T (dy . A^_i^T)
@@ -9,17 +10,22 @@
 //
 // GEMM view per sample n and per tile of `tt` whole frames (tt*V <= BN positions):
 //   out[n][m][q] = sum_{kc,tap} A(m,kc,tap) * B(n,kc,tap,q),   q = t_local*V + v
-// A (weights) and the B source window are staged in LDS per K-chunk of CK channels; every one of
-// the TAPS taps re-reads the SAME staged window at an offset of tap*V floats, so the 9x reuse of the
-// temporal convolution is served from LDS, not HBM.  For the aggregated variants the B chunk is first
-// multiplied by the (per-sample) VxV adjacency, also on the matrix cores, and kept in LDS.
+// * A: a tiny pack kernel first lays the weights out as the exact LDS image of every (row block, K chunk)
+//   (zero padded, tap-flipped / transposed as the mode needs), so the hot kernel stages A with contiguous float4.
+// * B: per K-chunk of CK channels the SOURCE WINDOW (tt+taps-1 frames) is staged in LDS once and every tap reads the
+//   same window at +tap*V floats: the 9x reuse of the temporal convolution is served from LDS, not HBM.
+//   For the aggregated variants the chunk is first multiplied by the sample's padded VxV adjacency on the matrix
+//   cores and kept in LDS.
+// * Software pipeline (register prefetch): the global loads of chunk k+1 are issued before the matrix-core loop of
+//   chunk k and committed to LDS after it, so HBM/L2 latency hides under the MFMAs; operand fragments are read one
+//   step ahead of the MFMAs that use them.
 #include "agcn_common.h"
 
 namespace {
 
 struct ConvGemmArgs {
   const float* in;
-  const float* w;
+  const float* wp;     // packed weight images [mblocks][nchunks][KK][BM]
   const float* bias;
   float* out;
   const float* adj;    // AGG: (N,3,V,V)
@@ -31,24 +37,52 @@ struct ConvGemmArgs {
   const float* xin;    // DADJ: x (N,C,P)
   float* dadj;         // DADJ: partial buffer
   int N, M, Kinner, in_rows;
-  int V, T_src, T_out, stride, tt, ntiles;
-  int FW;              // frames staged per window row
-  int WLP;             // Bx row pitch (floats)
-  long sa_m, sa_i, sa_c;
+  int V, T_src, T_out, tt, ntiles;   // T_out = number of output frame slots tau this launch covers
+  int src_stride, f_off;             // first source frame of a tile: t0*src_stride + f_off
+  int out_fs, out_fo, T_full;        // output frame = tau*out_fs + out_fo ; T_full = frames of the out tensor
+  int FW, WLP;
   int accumulate;
-  int C;               // DADJ: channels of x
-  int off_bx, off_bg, off_adj;   // LDS offsets (floats)
+  int C;                             // DADJ: channels of x
+  int nchunks;
+  int off_bx, off_bg, off_adj;       // LDS offsets (floats)
 };
 
-__device__ __forceinline__ int floordiv2(int x) { return x >> 1; }   // arithmetic shift = floor
+struct PackArgs {
+  const float* w;
+  float* wp;
+  int M, Kinner, nchunks;
+  long sa_m, sa_i, sa_c;
+  int tap_mul, tap_add, tap_flip_from;   // weight tap = tap_flip_from >= 0 ? tap_flip_from - (j*tap_mul+tap_add) : j
+};
 
-template <int MODE, int TAPS, int AGG, bool S2, int WM, int WN, int TM, int TN, int CK, int EPI>
+// wp[((mb*nchunks + ch)*KK + kk)*BM + ml],  kk = (i*CK + kcl)*TAPS + j
+template <int TAPS, int NSUB, int CK, int BM>
+__global__ void __launch_bounds__(256) pack_weights_kernel(const PackArgs p) {
+  constexpr int KK = NSUB * CK * TAPS;
+  const int ch = blockIdx.x % p.nchunks, mb = blockIdx.x / p.nchunks;
+  float* dst = p.wp + (long)blockIdx.x * KK * BM;
+  for (int e = threadIdx.x; e < KK * BM; e += 256) {
+    const int kk = e / BM, ml = e - kk * BM;
+    const int i = kk / (CK * TAPS), r = kk - i * (CK * TAPS);
+    const int kcl = r / TAPS, j = r - kcl * TAPS;
+    const int m = mb * BM + ml, kc = ch * CK + kcl;
+    const int gt = p.tap_flip_from >= 0 ? (p.tap_flip_from - (j * p.tap_mul + p.tap_add)) : j;
+    float v = 0.f;
+    if (m < p.M && kc < p.Kinner) v = p.w[(long)m * p.sa_m + (long)i * p.sa_i + (long)kc * p.sa_c + gt];
+    dst[e] = v;
+  }
+}
+
+// WB = max number of 64-float column blocks of a staged window row (compile-time bound of the prefetch registers)
+template <int TAPS, int AGG, int WM, int WN, int TM, int TN, int CK, int WB, int EPI>
 __global__ void __launch_bounds__(WM* WN * 64) conv_gemm_kernel(const ConvGemmArgs a) {
   constexpr int NW = WM * WN, NT = NW * 64;
-  constexpr int BM = WM * TM * 32, BMP = BM + 1;
+  constexpr int BM = WM * TM * 32;
   constexpr int NSUB = AGG ? 3 : 1;
-  constexpr int PAD = (TAPS - 1) / 2;
-  constexpr int KK = NSUB * CK * TAPS;   // rows of the staged A chunk
+  constexpr int KK = NSUB * CK * TAPS;       // rows of the staged A chunk
+  constexpr int N4 = KK * BM / 4;            // float4s of one A image
+  constexpr int EA = (N4 + NT - 1) / NT;     // A float4 per thread
+  constexpr int RPW = (CK + NW - 1) / NW;    // B rows per wave
   static_assert(CK % 2 == 0, "CK must be even");
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* Aw = smem;
@@ -68,29 +102,19 @@ __global__ void __launch_bounds__(WM* WN * 64) conv_gemm_kernel(const ConvGemmAr
   const int tvalid = min(tt, a.T_out - t0);
   const int nvalid = tvalid * V;
   const int Psrc = a.T_src * V;
-  const int Pout = a.T_out * V;
-
-  int f0;
-  if (AGG) f0 = t0;
-  else if (MODE == 0) f0 = t0 * a.stride - PAD;
-  else if (!S2) f0 = t0 - PAD;
-  else f0 = floordiv2(t0 - PAD);
-  const int hb0 = S2 ? (t0 - PAD - 2 * f0) : 0;
+  const int f0 = t0 * a.src_stride + a.f_off;
   const int WL = a.FW * V;
   const int WLP = a.WLP;
 
-  // per-lane B offsets for the TN position tiles of this wave
-  int boff[TN], vq[TN], hbq[TN];
+  // per-lane B offsets / output offsets for the TN position tiles of this wave
+  int boff[TN], ooff[TN];
 #pragma unroll
   for (int tn = 0; tn < TN; ++tn) {
     int q = (wn * TN + tn) * 32 + lr;
-    if (q >= ttv) q = 0;              // padding lanes read position 0; results are discarded
+    if (q >= ttv) q = 0;              // padding lanes read position 0; their results are discarded
     const int tl = q / V, v = q - tl * V;
-    vq[tn] = v;
-    hbq[tn] = hb0 + tl;
-    if (AGG) boff[tn] = q;
-    else if (MODE == 0) boff[tn] = tl * a.stride * V + v;
-    else boff[tn] = q;
+    boff[tn] = AGG ? q : (tl * a.src_stride * V + v);
+    ooff[tn] = ((t0 + tl) * a.out_fs + a.out_fo) * V + v;
   }
 
   if (AGG) {
@@ -100,9 +124,10 @@ __global__ void __launch_bounds__(WM* WN * 64) conv_gemm_kernel(const ConvGemmAr
     for (int e = tid; e < 3 * VP * 32; e += NT) {
       const int i = e / (VP * 32), r = e - i * (VP * 32);
       const int u = r >> 5, col = r & 31;
-      float val = 0.f;
-      if (u < V && col < V) val = (AGG == 1) ? adjn[(i * V + u) * V + col] : adjn[(i * V + col) * V + u];
-      adjp[e] = val;
+      const bool ok = u < V && col < V;
+      const int gi = ok ? ((AGG == 1) ? ((i * V + u) * V + col) : ((i * V + col) * V + u)) : 0;
+      const float t = adjn[gi];
+      adjp[e] = ok ? t : 0.f;
     }
   }
 
@@ -114,98 +139,71 @@ __global__ void __launch_bounds__(WM* WN * 64) conv_gemm_kernel(const ConvGemmAr
 #pragma unroll
       for (int j = 0; j < 16; ++j) acc[tm][tn][j] = 0.f;
 
-  const int nchunks = (a.Kinner + CK - 1) / CK;
-  for (int ch = 0; ch < nchunks; ++ch) {
+  // ---- prefetch registers ----
+  f32x4 ra[EA];
+  float rb[RPW][WB];
+  const f32x4* wp4 = reinterpret_cast<const f32x4*>(a.wp) + (long)blockIdx.y * a.nchunks * N4;
+  const int g0 = f0 * V;
+
+  // NOTE: the loaded values are kept RAW in registers; range predicates are re-evaluated at commit time, so
+  // nothing consumes a load result before the matrix-core loop it is meant to hide under.
+  auto issue_loads = [&](int ch) __attribute__((always_inline)) {
+    const f32x4* src = wp4 + (long)ch * N4;
+#pragma unroll
+    for (int u = 0; u < EA; ++u) ra[u] = src[min(tid + u * NT, N4 - 1)];
     const int kc0 = ch * CK;
-    __syncthreads();   // every wave is done reading the previous chunk
-    // ---- stage A chunk: Aw[kk][m_local]; loads are issued in batches of AU before any LDS store so that
-    //      AU global requests are in flight per lane (a load->store->load chain is latency-bound) ----
-    {
-      constexpr int AU = 6;
-      constexpr int TOTAL = BM * KK;
-      for (int e0 = tid; e0 < TOTAL; e0 += NT * AU) {
-        float val[AU];
-        int dst[AU];
 #pragma unroll
-        for (int u = 0; u < AU; ++u) {
-          const int e = min(e0 + u * NT, TOTAL - 1);
-          int ml, i, kcl, gt, row;
-          if (MODE == 0) {
-            ml = e / KK;
-            const int kk = e - ml * KK;
-            i = kk / (CK * TAPS);
-            const int r = kk - i * (CK * TAPS);
-            kcl = r / TAPS;
-            gt = r - kcl * TAPS;
-            row = kk;
-          } else {
-            const int kkc = e / (BM * TAPS), r = e - kkc * (BM * TAPS);
-            ml = r / TAPS;
-            gt = r - ml * TAPS;
-            i = kkc / CK;
-            kcl = kkc - i * CK;
-            row = kkc * TAPS + (TAPS - 1 - gt);
-          }
-          const int m = m0 + ml, kc = kc0 + kcl;
-          const bool ok = m < a.M && kc < a.Kinner;
-          const long gi = ok ? ((long)m * a.sa_m + (long)i * a.sa_i + (long)kc * a.sa_c + gt) : 0;
-          const float t = a.w[gi];
-          val[u] = ok ? t : 0.f;
-          dst[u] = row * BMP + ml;
-        }
+    for (int j = 0; j < RPW; ++j) {
+      const int kcl = wave + j * NW;
+      const bool rok = kcl < CK && (kc0 + kcl) < a.Kinner;
+      const float* rowp = a.in + ((long)n * a.in_rows + (rok ? (kc0 + kcl) : 0)) * Psrc;
 #pragma unroll
-        for (int u = 0; u < AU; ++u)
-          if (e0 + u * NT < TOTAL) Aw[dst[u]] = val[u];
+      for (int u = 0; u < WB; ++u) {
+        const int r = lane + 64 * u;
+        const int gp = g0 + r;
+        const bool ok = rok && r < WL && gp >= 0 && gp < Psrc;
+        rb[j][u] = rowp[ok ? gp : 0];
       }
     }
-    // ---- stage B source window: Bx[kc_local][r], r = (f - f0)*V + v, zero outside [0,T_src) ----
-    {
-      constexpr int RPW = (CK + NW - 1) / NW;            // rows per wave
-      constexpr int RU = (RPW >= 8) ? 1 : (8 / RPW);     // column blocks in flight per row
-      const float* rowp[RPW];
-      bool rok[RPW];
+  };
+  auto commit_lds = [&](int ch) __attribute__((always_inline)) {
 #pragma unroll
-      for (int j = 0; j < RPW; ++j) {
-        const int kcl = wave + j * NW;
-        rok[j] = kcl < CK && (kc0 + kcl) < a.Kinner;
-        rowp[j] = a.in + ((long)n * a.in_rows + (rok[j] ? (kc0 + kcl) : 0)) * Psrc;
-      }
-      const int g0 = f0 * V;
-      for (int r0 = lane; r0 < WL; r0 += 64 * RU) {
-        float val[RPW][RU];
+    for (int u = 0; u < EA; ++u)
+      if (tid + u * NT < N4) reinterpret_cast<f32x4*>(Aw)[tid + u * NT] = ra[u];
+    const int kc0 = ch * CK;
 #pragma unroll
-        for (int j = 0; j < RPW; ++j)
+    for (int j = 0; j < RPW; ++j) {
+      const int kcl = wave + j * NW;
+      const bool rok = kcl < CK && (kc0 + kcl) < a.Kinner;
 #pragma unroll
-          for (int u = 0; u < RU; ++u) {
-            const int r = r0 + 64 * u;
-            const int gp = g0 + r;
-            const bool ok = rok[j] && r < WL && gp >= 0 && gp < Psrc;
-            const float t = rowp[j][ok ? gp : 0];
-            val[j][u] = ok ? t : 0.f;
-          }
-#pragma unroll
-        for (int j = 0; j < RPW; ++j)
-#pragma unroll
-          for (int u = 0; u < RU; ++u) {
-            const int r = r0 + 64 * u;
-            const int kcl = wave + j * NW;
-            if (kcl < CK && r < WL) Bx[kcl * WLP + r] = val[j][u];
-          }
+      for (int u = 0; u < WB; ++u) {
+        const int r = lane + 64 * u;
+        const int gp = g0 + r;
+        const bool ok = rok && gp >= 0 && gp < Psrc;
+        if (kcl < CK && r < WL) Bx[kcl * WLP + r] = ok ? rb[j][u] : 0.f;
       }
     }
+  };
+
+  const int nchunks = a.nchunks;
+  if (nchunks > 0) issue_loads(0);
+  for (int ch = 0; ch < nchunks; ++ch) {
+    __syncthreads();                       // every wave is done reading the previous chunk from LDS
+    commit_lds(ch);
+    if (ch + 1 < nchunks) issue_loads(ch + 1);   // in flight during this chunk's matrix-core loop
     __syncthreads();
     if (AGG) {
       // Bg[i][c_local][q] = sum_u Bx[c_local][t*V+u] * adj_i[u][v]   (rows r=(c_local,t), 32 per MFMA tile)
       const int nrows = CK * tt;
       const int nrt = (nrows + 31) >> 5;
       const int VS = (V + 1) >> 1;
+      const int VP = 2 * VS;
       for (int tl = wave; tl < 3 * nrt; tl += NW) {
         const int i = tl / nrt, rt = tl - i * nrt;
         const int row = min(rt * 32 + lr, nrows - 1);
         f32x16 d;
 #pragma unroll
         for (int j = 0; j < 16; ++j) d[j] = 0.f;
-        const int VP = 2 * VS;
         for (int s = 0; s < VS; ++s) {
           const int u = 2 * s + h;
           float av = Bx[row * V + min(u, V - 1)];
@@ -221,31 +219,37 @@ __global__ void __launch_bounds__(WM* WN * 64) conv_gemm_kernel(const ConvGemmAr
       }
       __syncthreads();
     }
-    // ---- matrix-core contraction over this chunk ----
+    // ---- matrix-core contraction over this chunk; operands are fetched one step ahead ----
     constexpr int KP = (NSUB * CK) / 2;
+    const float* Bsrc = AGG ? Bg : Bx;
+    const int BP = AGG ? ttv : WLP;
+    const float* Arow = Aw + (wm * TM) * 32 + lr;
+    float av[TM], bv[TN];
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm) av[tm] = Arow[(h * TAPS) * BM + tm * 32];
+#pragma unroll
+    for (int tn = 0; tn < TN; ++tn) bv[tn] = Bsrc[h * BP + boff[tn]];
+#pragma unroll 1
     for (int kp = 0; kp < KP; ++kp) {
       const int krow = 2 * kp + h;
 #pragma unroll
       for (int tap = 0; tap < TAPS; ++tap) {
-        float av[TM], bv[TN];
+        // next step (clamped at the end: a harmless re-read)
+        const int ntap = (tap == TAPS - 1) ? 0 : tap + 1;
+        const int nkrow = (tap == TAPS - 1) ? min(krow + 2, 2 * (KP - 1) + h) : krow;
+        float an[TM], bn[TN];
 #pragma unroll
-        for (int tm = 0; tm < TM; ++tm) av[tm] = Aw[(krow * TAPS + tap) * BMP + (wm * TM + tm) * 32 + lr];
+        for (int tm = 0; tm < TM; ++tm) an[tm] = Arow[(nkrow * TAPS + ntap) * BM + tm * 32];
 #pragma unroll
-        for (int tn = 0; tn < TN; ++tn) {
-          if (AGG) {
-            bv[tn] = Bg[krow * ttv + boff[tn]];
-          } else if (!S2) {
-            bv[tn] = Bx[krow * WLP + boff[tn] + tap * V];
-          } else {
-            const int num = hbq[tn] + tap;
-            const float val = Bx[krow * WLP + (num >> 1) * V + vq[tn]];
-            bv[tn] = (num & 1) ? 0.f : val;
-          }
-        }
+        for (int tn = 0; tn < TN; ++tn) bn[tn] = Bsrc[nkrow * BP + boff[tn] + (AGG ? 0 : ntap * V)];
 #pragma unroll
         for (int tm = 0; tm < TM; ++tm)
 #pragma unroll
           for (int tn = 0; tn < TN; ++tn) acc[tm][tn] = mfma32(av[tm], bv[tn], acc[tm][tn]);
+#pragma unroll
+        for (int tm = 0; tm < TM; ++tm) av[tm] = an[tm];
+#pragma unroll
+        for (int tn = 0; tn < TN; ++tn) bv[tn] = bn[tn];
       }
     }
   }
@@ -253,44 +257,73 @@ __global__ void __launch_bounds__(WM* WN * 64) conv_gemm_kernel(const ConvGemmAr
   if (EPI == 0) {
     // ---- store (+bias, +accumulate, +masked addends) and per-channel (sum, sumsq) partials ----
     float* red = smem;   // aliases Aw: [WN][2][BM]
+    const long Pfull = (long)a.T_full * V;
     if (a.stats) __syncthreads();
+    const bool has_extra = a.accumulate || a.add1 || a.add2;   // kernel-uniform
 #pragma unroll
     for (int tm = 0; tm < TM; ++tm) {
 #pragma unroll
-      for (int j = 0; j < 16; ++j) {
-        const int ml = (wm * TM + tm) * 32 + mfma_row(j, h);
-        const int m = m0 + ml;
-        const bool mok = m < a.M;
-        const float bval = (a.bias && mok) ? a.bias[m] : 0.f;
-        float bsum = 0.f, bsq = 0.f;
+      for (int jb = 0; jb < 4; ++jb) {
+        // 4 rows x TN columns per batch: all residual/accumulate loads of the batch are issued together, with
+        // clamped (always valid) addresses, instead of one exec-masked load -> wait per element
+        float ex[4][TN];
+        long idxs[4][TN];
+        bool oks[4][TN];
 #pragma unroll
-        for (int tn = 0; tn < TN; ++tn) {
-          const int q = (wn * TN + tn) * 32 + lr;
-          if (mok && q < nvalid) {
-            const long idx = ((long)n * a.M + m) * Pout + (long)t0 * V + q;
-            float val = acc[tm][tn][j] + bval;
-            if (a.accumulate) val += a.out[idx];
-            if (a.add1) {
-              float t = a.add1[idx];
-              if (a.mask1) t = (a.mask1[idx] > 0.f) ? t : 0.f;
-              val += t;
-            }
-            if (a.add2) {
-              float t = a.add2[idx];
-              if (a.mask2) t = (a.mask2[idx] > 0.f) ? t : 0.f;
-              val += t;
-            }
-            a.out[idx] = val;
-            bsum += val;
-            bsq += val * val;
+        for (int jj = 0; jj < 4; ++jj) {
+          const int m = m0 + (wm * TM + tm) * 32 + mfma_row(jb * 4 + jj, h);
+#pragma unroll
+          for (int tn = 0; tn < TN; ++tn) {
+            const int q = (wn * TN + tn) * 32 + lr;
+            oks[jj][tn] = (m < a.M) && (q < nvalid);
+            idxs[jj][tn] = oks[jj][tn] ? (((long)n * a.M + m) * Pfull + ooff[tn]) : 0;
+            ex[jj][tn] = 0.f;
           }
         }
-        if (a.stats) {
-          bsum = half_sum(bsum);
-          bsq = half_sum(bsq);
-          if (lr == 0) {
-            red[(wn * 2 + 0) * BM + ml] = bsum;
-            red[(wn * 2 + 1) * BM + ml] = bsq;
+        if (has_extra) {
+#pragma unroll
+          for (int jj = 0; jj < 4; ++jj)
+#pragma unroll
+            for (int tn = 0; tn < TN; ++tn) {
+              const long idx = idxs[jj][tn];
+              float e = 0.f;
+              if (a.accumulate) e += a.out[idx];
+              if (a.add1) {
+                float t = a.add1[idx];
+                if (a.mask1) t = (a.mask1[idx] > 0.f) ? t : 0.f;
+                e += t;
+              }
+              if (a.add2) {
+                float t = a.add2[idx];
+                if (a.mask2) t = (a.mask2[idx] > 0.f) ? t : 0.f;
+                e += t;
+              }
+              ex[jj][tn] = e;
+            }
+        }
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) {
+          const int j = jb * 4 + jj;
+          const int ml = (wm * TM + tm) * 32 + mfma_row(j, h);
+          const int m = m0 + ml;
+          const float bval = (a.bias && m < a.M) ? a.bias[m] : 0.f;
+          float bsum = 0.f, bsq = 0.f;
+#pragma unroll
+          for (int tn = 0; tn < TN; ++tn) {
+            const float val = acc[tm][tn][j] + bval + ex[jj][tn];
+            if (oks[jj][tn]) {
+              a.out[idxs[jj][tn]] = val;
+              bsum += val;
+              bsq += val * val;
+            }
+          }
+          if (a.stats) {
+            bsum = half_sum(bsum);
+            bsq = half_sum(bsq);
+            if (lr == 0) {
+              red[(wn * 2 + 0) * BM + ml] = bsum;
+              red[(wn * 2 + 1) * BM + ml] = bsq;
+            }
           }
         }
       }
@@ -309,6 +342,7 @@ __global__ void __launch_bounds__(WM* WN * 64) conv_gemm_kernel(const ConvGemmAr
   } else {
     // ---- DADJ: dadj_i[u][v] = sum_{c,t} x[c][t,u] * acc[(i,c)][t,v]; rows of this block are m=(i,c) ----
     const int C = a.C;
+    const int Pout = a.T_full * V;
     float* Dg = smem;                 // [BM][ttv]
     float* Xs = smem + BM * ttv;      // [BM][ttv]
     float* red2 = Xs + BM * ttv;      // [NW][V*V]
@@ -323,12 +357,38 @@ __global__ void __launch_bounds__(WM* WN * 64) conv_gemm_kernel(const ConvGemmAr
           const int q = (wn * TN + tn) * 32 + lr;
           if (q < ttv) Dg[ml * ttv + q] = (q < nvalid && m0 + ml < a.M) ? acc[tm][tn][j] : 0.f;
         }
-    for (int ml = wave; ml < BM; ml += NW) {
-      const int m = m0 + ml;
-      const bool ok = m < a.M;
-      const int c = ok ? (m % C) : 0;
-      const float* src = a.xin + ((long)n * C + c) * Pout + (long)t0 * V;
-      for (int q = lane; q < ttv; q += 64) Xs[ml * ttv + q] = (ok && q < nvalid) ? src[q] : 0.f;
+    {
+      constexpr int XR = BM / NW;   // rows per wave
+      static_assert(XR % 8 == 0, "x tile rows per wave");
+      for (int jg = 0; jg < XR; jg += 8) {
+        for (int q0 = lane; q0 < ttv; q0 += 128) {
+          float val[8][2];
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            const int ml = wave + (jg + j) * NW;
+            const int m = m0 + ml;
+            const bool okr = m < a.M;
+            const int c = okr ? (m % C) : 0;
+            const float* src = a.xin + ((long)n * C + c) * Pout + (long)t0 * V;
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+              const int q = q0 + 64 * u;
+              const bool ok = okr && q < nvalid;
+              const float t = src[ok ? q : 0];
+              val[j][u] = ok ? t : 0.f;
+            }
+          }
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            const int ml = wave + (jg + j) * NW;
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+              const int q = q0 + 64 * u;
+              if (q < ttv) Xs[ml * ttv + q] = val[j][u];
+            }
+          }
+        }
+      }
     }
     __syncthreads();
     const int nmb = (C >= BM) ? (C / BM) : 1;
@@ -346,11 +406,11 @@ __global__ void __launch_bounds__(WM* WN * 64) conv_gemm_kernel(const ConvGemmAr
         const int c = c_lo + 2 * ap + h;
         const bool ok = (c < c_hi) && (lr < V);
         const int ml = i * C + min(c, c_hi - 1) - m0;
-        float av = Xs[ml * ttv + tl * V + lc];
-        float bv = Dg[ml * ttv + tl * V + lc];
-        av = ok ? av : 0.f;
-        bv = ok ? bv : 0.f;
-        d = mfma32(av, bv, d);
+        float xv = Xs[ml * ttv + tl * V + lc];
+        float gv = Dg[ml * ttv + tl * V + lc];
+        xv = ok ? xv : 0.f;
+        gv = ok ? gv : 0.f;
+        d = mfma32(xv, gv, d);
       }
 #pragma unroll
       for (int j = 0; j < 16; ++j) {
@@ -372,26 +432,26 @@ __global__ void __launch_bounds__(WM* WN * 64) conv_gemm_kernel(const ConvGemmAr
 }
 
 struct Geometry {
-  int tt, ntiles, FW, WLP, ttv;
-  size_t smem_bytes;
+  int tt, ntiles, FW, WLP, ttv, nchunks, nmb;
+  size_t smem_bytes, pack_floats;
   int off_bx, off_bg, off_adj;
 };
 
 // host-side tile geometry shared by the launcher and the workspace queries
-template <int MODE, int TAPS, int AGG, bool S2, int WM, int WN, int TM, int TN, int CK, int EPI>
-Geometry make_geometry(int V, int T_out, int stride) {
-  constexpr int BM = WM * TM * 32, BN = WN * TN * 32, BMP = BM + 1, NSUB = AGG ? 3 : 1, NW = WM * WN;
+template <int TAPS, int AGG, int WM, int WN, int TM, int TN, int CK, int EPI>
+Geometry make_geometry(int V, int T_out, int src_stride, int M, int Kinner) {
+  constexpr int BM = WM * TM * 32, BN = WN * TN * 32, NSUB = AGG ? 3 : 1, NW = WM * WN;
   Geometry g;
   g.tt = BN / V;
   if (g.tt > T_out) g.tt = T_out;
+  if (g.tt < 1) g.tt = 1;
   g.ttv = g.tt * V;
   g.ntiles = (T_out + g.tt - 1) / g.tt;
-  if (AGG) g.FW = g.tt;
-  else if (MODE == 0) g.FW = (g.tt - 1) * stride + TAPS;
-  else if (!S2) g.FW = g.tt + TAPS - 1;
-  else g.FW = (g.tt + TAPS - 1) / 2 + 2;
+  g.FW = AGG ? g.tt : ((g.tt - 1) * src_stride + TAPS);
   g.WLP = AGG ? g.ttv : g.FW * V + 8;
-  const int aw = NSUB * CK * TAPS * BMP;
+  g.nchunks = (Kinner + CK - 1) / CK;
+  g.nmb = (M + BM - 1) / BM;
+  const int aw = NSUB * CK * TAPS * BM;
   g.off_bx = (aw + 3) & ~3;
   const int bx = CK * g.WLP + 64;
   g.off_bg = g.off_bx + ((bx + 3) & ~3);
@@ -402,22 +462,40 @@ Geometry make_geometry(int V, int T_out, int stride) {
   size_t main_f = (size_t)g.off_adj + adjsz;
   size_t epi_f = (EPI == 0) ? (size_t)WN * 2 * BM : (size_t)2 * BM * g.ttv + (size_t)NW * V * V;
   g.smem_bytes = 4 * (main_f > epi_f ? main_f : epi_f);
+  g.pack_floats = (size_t)g.nmb * g.nchunks * aw;
   return g;
 }
 
-template <int MODE, int TAPS, int AGG, bool S2, int WM, int WN, int TM, int TN, int CK, int EPI>
-int launch_cfg(ConvGemmArgs a, hipStream_t stream) {
-  constexpr int BM = WM * TM * 32;
-  const Geometry g = make_geometry<MODE, TAPS, AGG, S2, WM, WN, TM, TN, CK, EPI>(a.V, a.T_out, a.stride);
+struct Problem {          // what differs between the entry points
+  ConvGemmArgs a;
+  const float* w;
+  long sa_m, sa_i, sa_c;
+  int tap_mul, tap_add, tap_flip_from;
+  void* ws;
+  size_t ws_bytes;
+};
+
+template <int TAPS, int AGG, int WM, int WN, int TM, int TN, int CK, int WB, int EPI>
+int launch_cfg(Problem& p, hipStream_t stream) {
+  constexpr int BM = WM * TM * 32, NSUB = AGG ? 3 : 1;
+  ConvGemmArgs a = p.a;
+  const Geometry g = make_geometry<TAPS, AGG, WM, WN, TM, TN, CK, EPI>(a.V, a.T_out, a.src_stride, a.M, a.Kinner);
   if (g.smem_bytes > 160 * 1024) return AGCN_ERR_UNSUPPORTED;
-  a.tt = g.tt;
-  a.ntiles = g.ntiles;
-  a.FW = g.FW;
-  a.WLP = g.WLP;
-  a.off_bx = g.off_bx;
-  a.off_bg = g.off_bg;
-  a.off_adj = g.off_adj;
-  auto kern = conv_gemm_kernel<MODE, TAPS, AGG, S2, WM, WN, TM, TN, CK, EPI>;
+  if (g.FW * a.V > WB * 64) return AGCN_ERR_UNSUPPORTED;
+  if (g.pack_floats * 4 > p.ws_bytes) return AGCN_ERR_WORKSPACE;
+  a.tt = g.tt; a.ntiles = g.ntiles; a.FW = g.FW; a.WLP = g.WLP; a.nchunks = g.nchunks;
+  a.off_bx = g.off_bx; a.off_bg = g.off_bg; a.off_adj = g.off_adj;
+  a.wp = (const float*)p.ws;
+  if (g.nchunks > 0) {
+    PackArgs pk;
+    pk.w = p.w; pk.wp = (float*)p.ws; pk.M = a.M; pk.Kinner = a.Kinner; pk.nchunks = g.nchunks;
+    pk.sa_m = p.sa_m; pk.sa_i = p.sa_i; pk.sa_c = p.sa_c;
+    pk.tap_mul = p.tap_mul; pk.tap_add = p.tap_add; pk.tap_flip_from = p.tap_flip_from;
+    hipLaunchKernelGGL((pack_weights_kernel<TAPS, NSUB, CK, BM>), dim3(g.nmb * g.nchunks), dim3(256), 0, stream, pk);
+    int rc = agcn_check_launch();
+    if (rc) return rc;
+  }
+  auto kern = conv_gemm_kernel<TAPS, AGG, WM, WN, TM, TN, CK, WB, EPI>;
   static bool attr_set = false;
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
@@ -425,15 +503,25 @@ int launch_cfg(ConvGemmArgs a, hipStream_t stream) {
     if (e != hipSuccess) return (int)e;
     attr_set = true;
   }
-  dim3 grid((unsigned)(a.N * g.ntiles), (unsigned)((a.M + BM - 1) / BM));
+  dim3 grid((unsigned)(a.N * g.ntiles), (unsigned)g.nmb);
   hipLaunchKernelGGL(kern, grid, dim3(WM * WN * 64), g.smem_bytes, stream, a);
   return agcn_check_launch();
 }
 
+template <int TAPS, int AGG, int WM, int WN, int TM, int TN, int CK, int EPI>
+size_t pack_bytes(int V, int T_out, int src_stride, int M, int Kinner) {
+  return 4 * make_geometry<TAPS, AGG, WM, WN, TM, TN, CK, EPI>(V, T_out, src_stride, M, Kinner).pack_floats;
+}
+
 // BM = 64 (4 waves) unless M is a multiple of 128 (8 waves, BM = 128)
-#define DISPATCH_BM(MODE, TAPS, AGG, S2, CK64, CK128, a, s)                                  \
-  (((a).M % 128 == 0) ? launch_cfg<MODE, TAPS, AGG, S2, 2, 4, 2, 2, CK128, 0>((a), (s))      \
-                      : launch_cfg<MODE, TAPS, AGG, S2, 1, 4, 2, 2, CK64, 0>((a), (s)))
+#define DISPATCH_BM(TAPS, AGG, CK64, CK128, WB, p, s)                                        \
+  (((p).a.M % 128 == 0) ? launch_cfg<TAPS, AGG, 2, 4, 2, 2, CK128, WB, 0>((p), (s))          \
+                        : launch_cfg<TAPS, AGG, 1, 4, 2, 2, CK64, WB, 0>((p), (s)))
+#define PACK_BYTES_BM(TAPS, AGG, CK64, CK128, V, T, ss, M, K)                                \
+  (((M) % 128 == 0) ? pack_bytes<TAPS, AGG, 2, 4, 2, 2, CK128, 0>(V, T, ss, M, K)            \
+                    : pack_bytes<TAPS, AGG, 1, 4, 2, 2, CK64, 0>(V, T, ss, M, K))
+
+constexpr int CK9 = 8, CK1 = 16, CKA = 8, CKD = 32;
 
 }  // namespace
 
@@ -456,79 +544,147 @@ int agcn_dadj_num_slots(int C, int V, int T) {
   return ntiles * nmb;
 }
 
+// bytes of workspace (packed weight images) the contraction entry points need; an upper bound over
+// forward / backward-data of a conv with these sizes, and over the aggregate/dadj kernels with C=Cin
+size_t agcn_conv_workspace(int Cin, int Cout, int T, int V, int taps, int stride) {
+  const int pad = (taps - 1) / 2;
+  const int To = (T + 2 * pad - taps) / stride + 1;
+  size_t b = 0, t;
+  if (taps == 9) {
+    b = PACK_BYTES_BM(9, 0, CK9, CK9, V, To, stride, Cout, Cin);
+    t = PACK_BYTES_BM(9, 0, CK9, CK9, V, T, 1, Cin, Cout); if (t > b) b = t;
+    t = PACK_BYTES_BM(5, 0, CK9, CK9, V, (T + 1) / 2, 1, Cin, Cout); if (t > b) b = t;
+  } else {
+    b = PACK_BYTES_BM(1, 0, CK1, CK1, V, To, stride, Cout, Cin);
+    t = PACK_BYTES_BM(1, 0, CK1, CK1, V, T, 1, Cin, Cout); if (t > b) b = t;
+  }
+  return b + 256;
+}
+size_t agcn_gcn_workspace(int C, int Cout, int T, int V) {
+  size_t b = PACK_BYTES_BM(1, 1, CKA, CKA, V, T, 1, Cout, C), t;
+  t = PACK_BYTES_BM(1, 2, CKA, CKA, V, T, 1, C, Cout); if (t > b) b = t;
+  t = pack_bytes<1, 0, 1, 4, 2, 1, CKD, 1>(V, T, 1, 3 * C, Cout); if (t > b) b = t;
+  return b + 256;
+}
+
 // y[n][o][t,v] = bias[o] + sum_{c,k} w[o][c][k] x[n][c][(t*stride + k - pad), v]      (unit_tcn conv, 1x1 convs)
-int agcn_conv_fwd(const float* x, const float* w, const float* bias, float* y, float* stats_part, int N, int Cin,
-                  int Cout, int T, int V, int taps, int stride, void* stream) {
-  if (!x || !w || !y || N <= 0 || Cin <= 0 || Cout <= 0 || T <= 0 || V <= 0 || V > 32) return AGCN_ERR_ARG;
+int agcn_conv_fwd(const float* x, const float* w, const float* bias, float* y, float* stats_part, void* workspace,
+                  size_t workspace_bytes, int N, int Cin, int Cout, int T, int V, int taps, int stride,
+                  void* stream) {
+  if (!x || !w || !y || !workspace || N <= 0 || Cin <= 0 || Cout <= 0 || T <= 0 || V <= 0 || V > 32)
+    return AGCN_ERR_ARG;
   if ((taps != 1 && taps != 9) || (stride != 1 && stride != 2)) return AGCN_ERR_UNSUPPORTED;
   const int pad = (taps - 1) / 2;
-  ConvGemmArgs a = {};
-  a.in = x; a.w = w; a.bias = bias; a.out = y; a.stats = stats_part;
+  Problem p = {};
+  ConvGemmArgs& a = p.a;
+  a.in = x; a.bias = bias; a.out = y; a.stats = stats_part;
   a.N = N; a.M = Cout; a.Kinner = Cin; a.in_rows = Cin; a.V = V;
-  a.T_src = T; a.T_out = (T + 2 * pad - taps) / stride + 1; a.stride = stride;
-  a.sa_m = (long)Cin * taps; a.sa_i = 0; a.sa_c = taps;
+  a.T_src = T; a.T_out = (T + 2 * pad - taps) / stride + 1; a.T_full = a.T_out;
+  a.src_stride = stride; a.f_off = -pad; a.out_fs = 1; a.out_fo = 0;
+  p.w = w; p.sa_m = (long)Cin * taps; p.sa_i = 0; p.sa_c = taps; p.tap_flip_from = -1;
+  p.ws = workspace; p.ws_bytes = workspace_bytes;
   hipStream_t s = (hipStream_t)stream;
-  if (taps == 9) return DISPATCH_BM(0, 9, 0, false, 16, 8, a, s);
-  return DISPATCH_BM(0, 1, 0, false, 32, 32, a, s);
+  if (taps == 9) return DISPATCH_BM(9, 0, CK9, CK9, 11, p, s);
+  return DISPATCH_BM(1, 0, CK1, CK1, 8, p, s);
 }
 
 // dx[n][c][t,v] (+)= sum_{o,k} w[o][c][k] dy[n][o][(t + pad - k)/stride, v]  (+ masked addends)
 int agcn_conv_bwd_data(const float* dy, const float* w, float* dx, int accumulate, const float* add1,
-                       const float* mask1, const float* add2, const float* mask2, int N, int Cin, int Cout, int T,
-                       int V, int taps, int stride, void* stream) {
-  if (!dy || !w || !dx || N <= 0 || Cin <= 0 || Cout <= 0 || T <= 0 || V <= 0 || V > 32) return AGCN_ERR_ARG;
+                       const float* mask1, const float* add2, const float* mask2, void* workspace,
+                       size_t workspace_bytes, int N, int Cin, int Cout, int T, int V, int taps, int stride,
+                       void* stream) {
+  if (!dy || !w || !dx || !workspace || N <= 0 || Cin <= 0 || Cout <= 0 || T <= 0 || V <= 0 || V > 32)
+    return AGCN_ERR_ARG;
   if ((taps != 1 && taps != 9) || (stride != 1 && stride != 2)) return AGCN_ERR_UNSUPPORTED;
   const int pad = (taps - 1) / 2;
-  ConvGemmArgs a = {};
-  a.in = dy; a.w = w; a.out = dx; a.accumulate = accumulate;
+  Problem p = {};
+  ConvGemmArgs& a = p.a;
+  a.in = dy; a.out = dx; a.accumulate = accumulate;
   a.add1 = add1; a.mask1 = mask1; a.add2 = add2; a.mask2 = mask2;
   a.N = N; a.M = Cin; a.Kinner = Cout; a.in_rows = Cout; a.V = V;
-  a.T_src = (T + 2 * pad - taps) / stride + 1; a.T_out = T; a.stride = stride;
-  a.sa_m = taps; a.sa_i = 0; a.sa_c = (long)Cin * taps;
+  a.T_src = (T + 2 * pad - taps) / stride + 1; a.T_full = T; a.src_stride = 1;
+  p.w = w; p.sa_m = taps; p.sa_i = 0; p.sa_c = (long)Cin * taps;
+  p.ws = workspace; p.ws_bytes = workspace_bytes;
   hipStream_t s = (hipStream_t)stream;
-  if (taps == 9) {
-    if (stride == 2) return DISPATCH_BM(1, 9, 0, true, 16, 8, a, s);
-    return DISPATCH_BM(1, 9, 0, false, 16, 8, a, s);
+  if (stride == 1) {
+    // dx[t] = sum_j W[taps-1-j] dy[t + j - pad]
+    a.T_out = T; a.out_fs = 1; a.out_fo = 0; a.f_off = -pad;
+    p.tap_mul = 1; p.tap_add = 0; p.tap_flip_from = taps - 1;
+    if (taps == 9) return DISPATCH_BM(9, 0, CK9, CK9, 8, p, s);
+    return DISPATCH_BM(1, 0, CK1, CK1, 8, p, s);
   }
-  if (stride == 2) return DISPATCH_BM(1, 1, 0, true, 32, 32, a, s);
-  return DISPATCH_BM(1, 1, 0, false, 32, 32, a, s);
+  // stride 2: output frames of parity `par` form a stride-1 problem over tau (t = 2*tau + par):
+  //   dx[2tau+par] = sum_j W[k = taps-1-(2j+par')] dy[tau + j + off]   with only the taps of matching parity
+  int rc;
+  if (taps == 9) {
+    // even t: tap' = 2j (j<5), source tau + j - 2 ; odd t: tap' = 2j+1 (j<4), source tau + j - 1
+    a.T_out = (T + 1) / 2; a.out_fs = 2; a.out_fo = 0; a.f_off = -2;
+    p.tap_mul = 2; p.tap_add = 0; p.tap_flip_from = 8;
+    rc = DISPATCH_BM(5, 0, CK9, CK9, 8, p, s);
+    if (rc) return rc;
+    a.T_out = T / 2; a.out_fo = 1; a.f_off = -1;
+    p.tap_add = 1;
+    if (a.T_out > 0) rc = DISPATCH_BM(4, 0, CK9, CK9, 8, p, s);
+    return rc;
+  }
+  // 1x1 stride 2: even t takes dy[t/2]; odd t receives no signal (zero + addends)
+  a.T_out = (T + 1) / 2; a.out_fs = 2; a.out_fo = 0; a.f_off = 0;
+  p.tap_mul = 1; p.tap_add = 0; p.tap_flip_from = 0;
+  rc = DISPATCH_BM(1, 0, CK1, CK1, 8, p, s);
+  if (rc) return rc;
+  a.T_out = T / 2; a.out_fo = 1; a.Kinner = 0;      // no K chunks: the epilogue writes 0 (+accumulate/addends)
+  if (a.T_out > 0) rc = DISPATCH_BM(1, 0, CK1, CK1, 8, p, s);
+  return rc;
 }
 
 // y[n][o][t,v] = bias[o] + sum_i sum_c wcat[o][i*C+c] * sum_u x[n][c][t,u] adj[n][i][u][v]
 int agcn_gcn_aggregate_project_fwd(const float* x, const float* adj, const float* wcat, const float* bias, float* y,
-                                   float* stats_part, int N, int C, int Cout, int T, int V, void* stream) {
-  if (!x || !adj || !wcat || !y || N <= 0 || C <= 0 || Cout <= 0 || T <= 0 || V <= 0 || V > 32) return AGCN_ERR_ARG;
-  ConvGemmArgs a = {};
-  a.in = x; a.w = wcat; a.bias = bias; a.out = y; a.adj = adj; a.stats = stats_part;
-  a.N = N; a.M = Cout; a.Kinner = C; a.in_rows = C; a.V = V; a.T_src = T; a.T_out = T; a.stride = 1;
-  a.sa_m = 3L * C; a.sa_i = C; a.sa_c = 1;
-  return DISPATCH_BM(0, 1, 1, false, 8, 8, a, (hipStream_t)stream);
+                                   float* stats_part, void* workspace, size_t workspace_bytes, int N, int C, int Cout,
+                                   int T, int V, void* stream) {
+  if (!x || !adj || !wcat || !y || !workspace || N <= 0 || C <= 0 || Cout <= 0 || T <= 0 || V <= 0 || V > 32)
+    return AGCN_ERR_ARG;
+  Problem p = {};
+  ConvGemmArgs& a = p.a;
+  a.in = x; a.bias = bias; a.out = y; a.adj = adj; a.stats = stats_part;
+  a.N = N; a.M = Cout; a.Kinner = C; a.in_rows = C; a.V = V; a.T_src = T; a.T_out = T; a.T_full = T;
+  a.src_stride = 1; a.f_off = 0; a.out_fs = 1; a.out_fo = 0;
+  p.w = wcat; p.sa_m = 3L * C; p.sa_i = C; p.sa_c = 1; p.tap_flip_from = -1;
+  p.ws = workspace; p.ws_bytes = workspace_bytes;
+  return DISPATCH_BM(1, 1, CKA, CKA, 4, p, (hipStream_t)stream);
 }
 
 // dx[n][c][t,u] (+)= sum_i sum_o wcat[o][i*C+c] * sum_v dy[n][o][t,v] adj[n][i][u][v]   (+ masked addends)
 int agcn_gcn_aggregate_project_bwd_data(const float* dy, const float* adj, const float* wcat, float* dx,
                                         int accumulate, const float* add1, const float* mask1, const float* add2,
-                                        const float* mask2, int N, int C, int Cout, int T, int V, void* stream) {
-  if (!dy || !adj || !wcat || !dx || N <= 0 || C <= 0 || Cout <= 0 || T <= 0 || V <= 0 || V > 32) return AGCN_ERR_ARG;
-  ConvGemmArgs a = {};
-  a.in = dy; a.w = wcat; a.out = dx; a.adj = adj; a.accumulate = accumulate;
+                                        const float* mask2, void* workspace, size_t workspace_bytes, int N, int C,
+                                        int Cout, int T, int V, void* stream) {
+  if (!dy || !adj || !wcat || !dx || !workspace || N <= 0 || C <= 0 || Cout <= 0 || T <= 0 || V <= 0 || V > 32)
+    return AGCN_ERR_ARG;
+  Problem p = {};
+  ConvGemmArgs& a = p.a;
+  a.in = dy; a.out = dx; a.adj = adj; a.accumulate = accumulate;
   a.add1 = add1; a.mask1 = mask1; a.add2 = add2; a.mask2 = mask2;
-  a.N = N; a.M = C; a.Kinner = Cout; a.in_rows = Cout; a.V = V; a.T_src = T; a.T_out = T; a.stride = 1;
-  a.sa_m = 1; a.sa_i = C; a.sa_c = 3L * C;
-  return DISPATCH_BM(1, 1, 2, false, 8, 8, a, (hipStream_t)stream);
+  a.N = N; a.M = C; a.Kinner = Cout; a.in_rows = Cout; a.V = V; a.T_src = T; a.T_out = T; a.T_full = T;
+  a.src_stride = 1; a.f_off = 0; a.out_fs = 1; a.out_fo = 0;
+  p.w = wcat; p.sa_m = 1; p.sa_i = C; p.sa_c = 3L * C; p.tap_flip_from = -1;
+  p.ws = workspace; p.ws_bytes = workspace_bytes;
+  return DISPATCH_BM(1, 2, CKA, CKA, 4, p, (hipStream_t)stream);
 }
 
 // dadj_part[n][i][slot][u][v] = sum over the slot's (c,t) of x[n][c][t,u] * (sum_o wcat[o][i*C+c] dy[n][o][t,v])
-int agcn_gcn_dadj(const float* dy, const float* wcat, const float* x, float* dadj_part, int N, int C, int Cout,
-                  int T, int V, void* stream) {
-  if (!dy || !wcat || !x || !dadj_part || N <= 0 || C <= 0 || Cout <= 0 || T <= 0 || V <= 0 || V > 32)
+int agcn_gcn_dadj(const float* dy, const float* wcat, const float* x, float* dadj_part, void* workspace,
+                  size_t workspace_bytes, int N, int C, int Cout, int T, int V, void* stream) {
+  if (!dy || !wcat || !x || !dadj_part || !workspace || N <= 0 || C <= 0 || Cout <= 0 || T <= 0 || V <= 0 || V > 32)
     return AGCN_ERR_ARG;
   if (C >= 64 && C % 64 != 0) return AGCN_ERR_UNSUPPORTED;
-  ConvGemmArgs a = {};
-  a.in = dy; a.w = wcat; a.xin = x; a.dadj = dadj_part;
-  a.N = N; a.M = 3 * C; a.Kinner = Cout; a.in_rows = Cout; a.V = V; a.T_src = T; a.T_out = T; a.stride = 1;
-  a.sa_m = 1; a.sa_i = 0; a.sa_c = 3L * C; a.C = C;
-  return launch_cfg<1, 1, 0, false, 1, 4, 2, 1, 32, 1>(a, (hipStream_t)stream);
+  Problem p = {};
+  ConvGemmArgs& a = p.a;
+  a.in = dy; a.xin = x; a.dadj = dadj_part;
+  a.N = N; a.M = 3 * C; a.Kinner = Cout; a.in_rows = Cout; a.V = V; a.T_src = T; a.T_out = T; a.T_full = T;
+  a.src_stride = 1; a.f_off = 0; a.out_fs = 1; a.out_fo = 0; a.C = C;
+  p.w = wcat; p.sa_m = 1; p.sa_i = 0; p.sa_c = 3L * C; p.tap_flip_from = -1;
+  p.ws = workspace; p.ws_bytes = workspace_bytes;
+  return launch_cfg<1, 0, 1, 4, 2, 1, CKD, 2, 1>(p, (hipStream_t)stream);
 }
 
 }  // extern "C"

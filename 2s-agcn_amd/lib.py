@@ -26,13 +26,15 @@ SIGNATURES = {
     "agcn_conv_num_tiles": (_I, [_I, _I]),
     "agcn_dadj_num_slots": (_I, [_I, _I, _I]),
     "agcn_scores_num_tiles": (_I, [_I, _I]),
-    "agcn_conv_fwd": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
-    "agcn_conv_bwd_data": (_I, [_P, _P, _P, _I, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
+    "agcn_conv_workspace": (_Z, [_I, _I, _I, _I, _I, _I]),
+    "agcn_gcn_workspace": (_Z, [_I, _I, _I, _I]),
+    "agcn_conv_fwd": (_I, [_P, _P, _P, _P, _P, _P, _Z, _I, _I, _I, _I, _I, _I, _I, _P]),
+    "agcn_conv_bwd_data": (_I, [_P, _P, _P, _I, _P, _P, _P, _P, _P, _Z, _I, _I, _I, _I, _I, _I, _I, _P]),
     "agcn_conv_bwd_weight_workspace": (_Z, [_I, _I, _I, _I, _I, _I, _I]),
     "agcn_conv_bwd_weight": (_I, [_P, _P, _P, _P, _Z, _I, _I, _I, _I, _I, _I, _I, _P]),
-    "agcn_gcn_aggregate_project_fwd": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
-    "agcn_gcn_aggregate_project_bwd_data": (_I, [_P, _P, _P, _P, _I, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
-    "agcn_gcn_dadj": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
+    "agcn_gcn_aggregate_project_fwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _Z, _I, _I, _I, _I, _I, _P]),
+    "agcn_gcn_aggregate_project_bwd_data": (_I, [_P, _P, _P, _P, _I, _P, _P, _P, _P, _P, _Z, _I, _I, _I, _I, _I, _P]),
+    "agcn_gcn_dadj": (_I, [_P, _P, _P, _P, _P, _Z, _I, _I, _I, _I, _I, _P]),
     "agcn_gcn_project_bwd_weight_workspace": (_Z, [_I, _I, _I, _I, _I]),
     "agcn_gcn_project_bwd_weight": (_I, [_P, _P, _P, _P, _P, _Z, _I, _I, _I, _I, _I, _P]),
     "agcn_adjacency_fwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),

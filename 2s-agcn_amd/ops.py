@@ -22,6 +22,21 @@ def _empty(shape, like):
     return torch.empty(shape, dtype=torch.float32, device=like.device)
 
 
+def _ws(nbytes, like):
+    """Byte workspace (packed weight images etc.) from the caching allocator."""
+    return torch.empty((int(nbytes) + 3) // 4, dtype=torch.float32, device=like.device)
+
+
+def _conv_ws(Cin, Cout, T, V, taps, stride, like):
+    n = _L().agcn_conv_workspace(Cin, Cout, T, V, taps, stride)
+    return _ws(n, like), n
+
+
+def _gcn_ws(C, Cout, T, V, like):
+    n = _L().agcn_gcn_workspace(C, Cout, T, V)
+    return _ws(n, like), n
+
+
 def _scratch(width, like):
     """Scratch for the two-stage column reductions (agcn_colsum_scratch_bytes)."""
     nbytes = _L().agcn_colsum_scratch_bytes(int(width))
@@ -48,8 +63,9 @@ def conv_fwd(x, w, b, stride=1, want_stats=False):
     if want_stats:
         nt = _L().agcn_conv_num_tiles(V, To)
         stats = _empty((N * nt, 2, Cout), x)
-    _lib.check(_L().agcn_conv_fwd(_lib.ptr(x), _lib.ptr(w), _lib.ptr(b), _lib.ptr(y), _lib.ptr(stats),
-                                  N, Cin, Cout, T, V, taps, stride, _lib.stream()), "agcn_conv_fwd")
+    ws, nb = _conv_ws(Cin, Cout, T, V, taps, stride, x)
+    _lib.check(_L().agcn_conv_fwd(_lib.ptr(x), _lib.ptr(w), _lib.ptr(b), _lib.ptr(y), _lib.ptr(stats), ws.data_ptr(),
+                                  nb, N, Cin, Cout, T, V, taps, stride, _lib.stream()), "agcn_conv_fwd")
     return y, stats
 
 
@@ -58,9 +74,10 @@ def conv_bwd_data(dy, w, x_shape, stride=1, out=None, accumulate=False, add1=Non
     N, Cin, T, V = x_shape
     Cout, _, taps, _ = w.shape
     dx = out if out is not None else _empty(x_shape, dy)
+    ws, nb = _conv_ws(Cin, Cout, T, V, taps, stride, dy)
     _lib.check(_L().agcn_conv_bwd_data(_lib.ptr(dy), _lib.ptr(w), _lib.ptr(dx), int(accumulate), _lib.ptr(add1),
-                                       _lib.ptr(mask1), _lib.ptr(add2), _lib.ptr(mask2), N, Cin, Cout, T, V, taps,
-                                       stride, _lib.stream()), "agcn_conv_bwd_data")
+                                       _lib.ptr(mask1), _lib.ptr(add2), _lib.ptr(mask2), ws.data_ptr(), nb, N, Cin,
+                                       Cout, T, V, taps, stride, _lib.stream()), "agcn_conv_bwd_data")
     return dx
 
 
@@ -97,8 +114,10 @@ def aggregate_project_fwd(x, adj, wcat, bias, want_stats=False):
     if want_stats:
         nt = _L().agcn_conv_num_tiles(V, T)
         stats = _empty((N * nt, 2, Cout), x)
+    ws, nb = _gcn_ws(C, Cout, T, V, x)
     _lib.check(_L().agcn_gcn_aggregate_project_fwd(_lib.ptr(x), _lib.ptr(adj), _lib.ptr(wcat), _lib.ptr(bias),
-                                                   _lib.ptr(y), _lib.ptr(stats), N, C, Cout, T, V, _lib.stream()),
+                                                   _lib.ptr(y), _lib.ptr(stats), ws.data_ptr(), nb, N, C, Cout, T, V,
+                                                   _lib.stream()),
                "agcn_gcn_aggregate_project_fwd")
     return y, stats
 
@@ -108,9 +127,11 @@ def aggregate_project_bwd_data(dy, adj, wcat, x_shape, out=None, accumulate=Fals
     N, C, T, V = x_shape
     Cout = wcat.shape[0]
     dx = out if out is not None else _empty(x_shape, dy)
+    ws, nb = _gcn_ws(C, Cout, T, V, dy)
     _lib.check(_L().agcn_gcn_aggregate_project_bwd_data(
         _lib.ptr(dy), _lib.ptr(adj), _lib.ptr(wcat), _lib.ptr(dx), int(accumulate), _lib.ptr(add1), _lib.ptr(mask1),
-        _lib.ptr(add2), _lib.ptr(mask2), N, C, Cout, T, V, _lib.stream()), "agcn_gcn_aggregate_project_bwd_data")
+        _lib.ptr(add2), _lib.ptr(mask2), ws.data_ptr(), nb, N, C, Cout, T, V, _lib.stream()),
+        "agcn_gcn_aggregate_project_bwd_data")
     return dx
 
 
@@ -132,8 +153,9 @@ def adjacency_bwd(dy, wcat, x, tp, P, alpha=None):
     Ci = tp.shape[1] // 6
     nslots = _L().agcn_dadj_num_slots(C, V, T)
     dpart = _empty((N, 3, nslots, V, V), x)
-    _lib.check(_L().agcn_gcn_dadj(_lib.ptr(dy), _lib.ptr(wcat), _lib.ptr(x), _lib.ptr(dpart), N, C, Cout, T, V,
-                                  _lib.stream()), "agcn_gcn_dadj")
+    ws, nb = _gcn_ws(C, Cout, T, V, x)
+    _lib.check(_L().agcn_gcn_dadj(_lib.ptr(dy), _lib.ptr(wcat), _lib.ptr(x), _lib.ptr(dpart), ws.data_ptr(), nb, N, C,
+                                  Cout, T, V, _lib.stream()), "agcn_gcn_dadj")
     dadj = _empty((N, 3, V, V), x)
     dS = _empty((N, 3, V, V), x)
     dPA = _empty((3, V, V), x)

@@ -48,13 +48,15 @@ int agcn_dadj_num_slots(int C, int V, int T);    /* slots per (sample, subset) o
  *           :73 (down conv), and the kernel_size=1 residual unit_tcn at :125.   taps in {1,9}, stride in {1,2}.
  * w: (Cout, Cin, taps, 1) as in the reference state_dict.  stats_part (optional, may be NULL): per-channel partial
  * (sum, sum of squares) of y, layout [N*agcn_conv_num_tiles][2][Cout], consumed by agcn_bn_stats_finalize. */
-int agcn_conv_fwd(const float* x, const float* w, const float* bias, float* y, float* stats_part, int N, int Cin,
-                  int Cout, int T, int V, int taps, int stride, void* stream);
+size_t agcn_conv_workspace(int Cin, int Cout, int T, int V, int taps, int stride); /* fwd and bwd_data (packed weights) */
+int agcn_conv_fwd(const float* x, const float* w, const float* bias, float* y, float* stats_part, void* workspace,
+                  size_t workspace_bytes, int N, int Cin, int Cout, int T, int V, int taps, int stride, void* stream);
 /* dx (+)= conv^T(dy) [+ add1*(mask1>0)] [+ add2*(mask2>0)]; add/mask are dx-shaped or NULL (mask NULL = no masking);
  * they fold the ReLU-masked identity-residual gradients (agcn.py:108-109,128-129) into the epilogue. */
 int agcn_conv_bwd_data(const float* dy, const float* w, float* dx, int accumulate, const float* add1,
-                       const float* mask1, const float* add2, const float* mask2, int N, int Cin, int Cout, int T,
-                       int V, int taps, int stride, void* stream);
+                       const float* mask1, const float* add2, const float* mask2, void* workspace,
+                       size_t workspace_bytes, int N, int Cin, int Cout, int T, int V, int taps, int stride,
+                       void* stream);
 size_t agcn_conv_bwd_weight_workspace(int N, int Cin, int Cout, int T, int V, int taps, int stride);
 int agcn_conv_bwd_weight(const float* dy, const float* x, float* dw, void* workspace, size_t workspace_bytes, int N,
                          int Cin, int Cout, int T, int V, int taps, int stride, void* stream);
@@ -63,17 +65,20 @@ int agcn_conv_bwd_weight(const float* dy, const float* x, float* dw, void* works
  * replaces agcn.py:103-105:  y = sum_i conv_d[i]( matmul(x.view(N,C*T,V), A^_i) )   (three bmm + three 1x1 convs + adds)
  * adj: (N,3,V,V) = A^ from agcn_adjacency_fwd ; wcat: (Cout, 3*C) = [Wd_0 | Wd_1 | Wd_2] ; bias: sum of the three
  * conv_d biases (or NULL). */
+size_t agcn_gcn_workspace(int C, int Cout, int T, int V);   /* aggregate fwd / bwd_data / dadj (packed weights) */
 int agcn_gcn_aggregate_project_fwd(const float* x, const float* adj, const float* wcat, const float* bias, float* y,
-                                   float* stats_part, int N, int C, int Cout, int T, int V, void* stream);
+                                   float* stats_part, void* workspace, size_t workspace_bytes, int N, int C, int Cout,
+                                   int T, int V, void* stream);
 int agcn_gcn_aggregate_project_bwd_data(const float* dy, const float* adj, const float* wcat, float* dx,
                                         int accumulate, const float* add1, const float* mask1, const float* add2,
-                                        const float* mask2, int N, int C, int Cout, int T, int V, void* stream);
+                                        const float* mask2, void* workspace, size_t workspace_bytes, int N, int C,
+                                        int Cout, int T, int V, void* stream);
 size_t agcn_gcn_project_bwd_weight_workspace(int N, int C, int Cout, int T, int V);
 int agcn_gcn_project_bwd_weight(const float* dy, const float* x, const float* adj, float* dwcat, void* workspace,
                                 size_t workspace_bytes, int N, int C, int Cout, int T, int V, void* stream);
 /* dadj_part: (N, 3, agcn_dadj_num_slots, V, V) partial adjacency gradients, summed by agcn_adjacency_bwd_softmax */
-int agcn_gcn_dadj(const float* dy, const float* wcat, const float* x, float* dadj_part, int N, int C, int Cout,
-                  int T, int V, void* stream);
+int agcn_gcn_dadj(const float* dy, const float* wcat, const float* x, float* dadj_part, void* workspace,
+                  size_t workspace_bytes, int N, int C, int Cout, int T, int V, void* stream);
 
 /* ---- adaptive adjacency ------------------------------------------------------------------------------------------------
  * replaces agcn.py:95,99-102:  A^_i = softmax_{dim -2}( theta_i^T phi_i / (Ci*T) ) + A_i + PA_i

@@ -136,8 +136,9 @@ def test_aggregate_project(case):
     from agcn_amd import lib
     nslots = L.agcn_dadj_num_slots(C, V, T)
     dpart = torch.empty((N, 3, nslots, V, V), device=dev)
-    lib.check(L.agcn_gcn_dadj(lib.ptr(dyg), lib.ptr(wg), lib.ptr(xg), lib.ptr(dpart), N, C, Cout, T, V,
-                              lib.stream()), 'dadj')
+    ws, nb = ops._gcn_ws(C, Cout, T, V, xg)
+    lib.check(L.agcn_gcn_dadj(lib.ptr(dyg), lib.ptr(wg), lib.ptr(xg), lib.ptr(dpart), ws.data_ptr(), nb, N, C, Cout, T,
+                              V, lib.stream()), 'dadj')
     assert rel(dpart.sum(2), adj.grad) < TOL
 
 

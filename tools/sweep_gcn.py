@@ -32,7 +32,7 @@ for (C, Cout) in [(64, 64), (128, 128), (256, 256), (64, 128), (128, 256), (3, 6
             dw = ops.project_bwd_weight(dyg, xg, ag, Cout)
             L = ops._L(); ns = L.agcn_dadj_num_slots(C, V, T)
             dpart = torch.empty((N, 3, ns, V, V), device=dev)
-            lib.check(L.agcn_gcn_dadj(lib.ptr(dyg), lib.ptr(wg), lib.ptr(xg), lib.ptr(dpart), N, C, Cout, T, V, lib.stream()), 'dadj')
+            ws, nb = ops._gcn_ws(C, Cout, T, V, xg); lib.check(L.agcn_gcn_dadj(lib.ptr(dyg), lib.ptr(wg), lib.ptr(xg), lib.ptr(dpart), ws.data_ptr(), nb, N, C, Cout, T, V, lib.stream()), 'dadj')
             e = (rel(yo, y), rel(dx, x.grad), rel(dw, wcat.grad), rel(dpart.sum(2), adj.grad))
             print((N, C, Cout, T, V), 'fwd %.1e dx %.1e dw %.1e dadj %.1e' % e, '' if max(e) < 1e-4 else '  <<<<<< FAIL')
 print('== unit isolation with GAP-like loss')
