@@ -2,9 +2,13 @@
 // the matrix cores:   dW[m][c][tap] = sum_{n, q} dy[n][m][q] * B(n, c, tap, q)
 // where B is the forward B operand (the shifted input window, or the aggregated x . A^_i for the
 // projection weights conv_d).  GEMM view: M = output channels, N = (c, tap), K = positions (n, t, v).
-// Each workgroup owns one (m-block, c-block) tile of dW and a contiguous share of the (n, frame-tile)
-// pairs (split-K); it writes one partial slab, and `wgrad_reduce_kernel` sums the slabs in a fixed order
-// (bitwise reproducible; no float atomics).
+//
+// A workgroup (8 waves) owns one (m-block, c-block) tile of dW and a contiguous share of the (n, frame-tile)
+// pairs (split-K).  Per pair it stages the dy tile and the input window in LDS; a wave owns one 32x32 (m, c)
+// tile for a group of taps (the A fragment is reused across the taps), the two wave halves of a SIMD pair split
+// the 9 taps 5/4 (or, for 1-tap problems, the positions).  Software pipeline: the global loads of pair p+1 are
+// issued before the matrix-core loop of pair p and committed to LDS after it.  Every wave group writes its own
+// partial slab and `wgrad_reduce_kernel` sums the slabs in a fixed order (bitwise reproducible; no atomics).
 #include "agcn_common.h"
 
 namespace {
@@ -22,14 +26,20 @@ struct WgradArgs {
   int off_bx, off_bg, off_adj, off_qoff;
 };
 
-// TAPS: 1 or 9 taps (plain) ; AGG: B = x . adj_i with the 3 subsets playing the role of taps
-template <int TAPS, int AGG, int MW, int CW, int TMr, int TNr>
-__global__ void __launch_bounds__(MW* CW * 64) conv_wgrad_kernel(const WgradArgs a) {
-  constexpr int NW = MW * CW, NT = NW * 64;
-  constexpr int BM = MW * TMr * 32, CB = CW * TNr * 32;
-  static_assert((BM / NW) % 8 == 0 && (CB / NW) % 8 == 0, "staging batches rows by 8");
+// TAPS: 1 or 9 taps (plain) ; AGG: B = x . adj_i with the 3 subsets playing the role of taps.
+// 8 waves = MW (m tiles) x CW (c tiles) x TH ; TH=2 splits the taps (KSPLIT=false) or the positions (KSPLIT=true).
+// WBX = 64-float column blocks of a window row (bound of the prefetch registers).
+template <int TAPS, int AGG, int MW, int CW, int TH, bool KSPLIT, int WBX>
+__global__ void __launch_bounds__(512) conv_wgrad_kernel(const WgradArgs a) {
+  constexpr int NW = 8, NT = 512;
+  static_assert(MW * CW * TH == NW, "8 waves");
+  constexpr int BM = MW * 32, CB = CW * 32;
   constexpr int NSUB = AGG ? 3 : 1;
   constexpr int PAD = (TAPS - 1) / 2;
+  constexpr bool TSPLIT = (TH == 2) && !KSPLIT;
+  constexpr int NTW = TSPLIT ? (TAPS + 1) / 2 : TAPS;     // taps per wave
+  constexpr int NACC = NSUB * NTW;
+  constexpr int RD = BM / NW, RB = CB / NW;               // dy / window rows per wave
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* Da = smem;
   float* Bx = smem + a.off_bx;
@@ -40,7 +50,9 @@ __global__ void __launch_bounds__(MW* CW * 64) conv_wgrad_kernel(const WgradArgs
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int lr = lane & 31, h = lane >> 5;
-  const int mw = wave % MW, cw = wave / MW;
+  const int th = wave / (MW * CW);
+  const int wmc = wave - th * (MW * CW);
+  const int mw = wmc % MW, cw = wmc / MW;
   const int ncb = (a.C + CB - 1) / CB;
   const int mb = blockIdx.x / ncb, cb = blockIdx.x - mb * ncb;
   const int m0 = mb * BM, c0 = cb * CB;
@@ -48,6 +60,10 @@ __global__ void __launch_bounds__(MW* CW * 64) conv_wgrad_kernel(const WgradArgs
   const int Psrc = a.T_src * V, Pout = a.T_out * V;
   const int WL = a.FW * V, WLP = a.WLP, DAP = a.DAP, GP = a.GP;
   const int KS = (ttv + 1) >> 1;
+  const int tap0 = TSPLIT ? th * NTW : 0;
+  const int ntaps = TSPLIT ? (th == 0 ? NTW : TAPS - NTW) : TAPS;
+  const int s_begin = KSPLIT ? (th * ((KS + 1) >> 1)) : 0;
+  const int s_end = KSPLIT ? min(KS, s_begin + ((KS + 1) >> 1)) : KS;
 
   for (int q = tid; q < 2 * KS + 2; q += NT) {
     int o = 0;
@@ -58,106 +74,98 @@ __global__ void __launch_bounds__(MW* CW * 64) conv_wgrad_kernel(const WgradArgs
     qoff[q] = o;
   }
 
-  f32x16 acc[TMr][TNr][NSUB * TAPS];
+  f32x16 acc[NACC];
 #pragma unroll
-  for (int x = 0; x < TMr; ++x)
+  for (int z = 0; z < NACC; ++z)
 #pragma unroll
-    for (int y = 0; y < TNr; ++y)
+    for (int j = 0; j < 16; ++j) acc[z][j] = 0.f;
+
+  float rda[RD][2];
+  float rbx[RB][WBX];
+
+  auto pair_geom = [&](int p, int& n, int& t0, int& nvalid, int& g0) __attribute__((always_inline)) {
+    n = p / a.ntiles;
+    const int tile = p - n * a.ntiles;
+    t0 = tile * tt;
+    nvalid = min(tt, a.T_out - t0) * V;
+    g0 = (AGG ? t0 : (t0 * a.stride - PAD)) * V;
+  };
+  // raw loads into registers (predicates are re-evaluated at commit time, so nothing waits on them early)
+  auto issue_loads = [&](int p) __attribute__((always_inline)) {
+    int n, t0, nvalid, g0;
+    pair_geom(p, n, t0, nvalid, g0);
 #pragma unroll
-      for (int z = 0; z < NSUB * TAPS; ++z)
+    for (int j = 0; j < RD; ++j) {
+      const int m = m0 + wave + j * NW;
+      const bool okr = m < a.M;
+      const float* src = a.dy + ((long)n * a.M + (okr ? m : 0)) * Pout + (long)t0 * V;
 #pragma unroll
-        for (int j = 0; j < 16; ++j) acc[x][y][z][j] = 0.f;
+      for (int u = 0; u < 2; ++u) {
+        const int q = lane + 64 * u;
+        rda[j][u] = src[(okr && q < nvalid) ? q : 0];
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < RB; ++j) {
+      const int c = c0 + wave + j * NW;
+      const bool okr = c < a.C;
+      const float* src = a.in + ((long)n * a.C + (okr ? c : 0)) * Psrc;
+#pragma unroll
+      for (int u = 0; u < WBX; ++u) {
+        const int r = lane + 64 * u;
+        const int gp = g0 + r;
+        rbx[j][u] = src[(okr && r < WL && gp >= 0 && gp < Psrc) ? gp : 0];
+      }
+    }
+  };
+  auto commit_lds = [&](int p) __attribute__((always_inline)) {
+    int n, t0, nvalid, g0;
+    pair_geom(p, n, t0, nvalid, g0);
+#pragma unroll
+    for (int j = 0; j < RD; ++j) {
+      const int ml = wave + j * NW;
+      const bool okr = (m0 + ml) < a.M;
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const int q = lane + 64 * u;
+        if (q < DAP) Da[ml * DAP + q] = (okr && q < nvalid) ? rda[j][u] : 0.f;
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < RB; ++j) {
+      const int cl = wave + j * NW;
+      const bool okr = (c0 + cl) < a.C;
+#pragma unroll
+      for (int u = 0; u < WBX; ++u) {
+        const int r = lane + 64 * u;
+        const int gp = g0 + r;
+        if (r < WLP) Bx[cl * WLP + r] = (okr && r < WL && gp >= 0 && gp < Psrc) ? rbx[j][u] : 0.f;
+      }
+    }
+  };
 
   const int total_pairs = a.N * a.ntiles;
   const int p_begin = blockIdx.y * a.pairs_per_split;
   const int p_end = min(total_pairs, p_begin + a.pairs_per_split);
   int last_n = -1;
+  if (p_begin < p_end) issue_loads(p_begin);
   for (int p = p_begin; p < p_end; ++p) {
-    const int n = p / a.ntiles, tile = p - n * a.ntiles;
-    const int t0 = tile * tt;
-    const int nvalid = min(tt, a.T_out - t0) * V;
-    const int f0 = AGG ? t0 : (t0 * a.stride - PAD);
-    __syncthreads();
-    // ---- stage dy tile: Da[m_local][q] (zero beyond the valid positions, incl. the pad column).
-    //      Loads are issued in batches (8 rows x column blocks) before the LDS stores: many requests in flight. ----
-    {
-      constexpr int RPW = BM / NW;        // rows per wave (16 or 32)
-      constexpr int RG = 8;               // rows per batch
-      const long dybase = (long)n * a.M * Pout + (long)t0 * V;
-      for (int jg = 0; jg < RPW; jg += RG) {
-        for (int q0 = lane; q0 < DAP; q0 += 128) {
-          float val[RG][2];
-#pragma unroll
-          for (int j = 0; j < RG; ++j) {
-            const int ml = wave + (jg + j) * NW;
-            const int m = m0 + ml;
-            const bool okr = m < a.M;
-            const float* src = a.dy + dybase + (long)(okr ? m : 0) * Pout;
-#pragma unroll
-            for (int u = 0; u < 2; ++u) {
-              const int q = q0 + 64 * u;
-              const bool ok = okr && q < nvalid;
-              const float t = src[ok ? q : 0];
-              val[j][u] = ok ? t : 0.f;
-            }
-          }
-#pragma unroll
-          for (int j = 0; j < RG; ++j) {
-            const int ml = wave + (jg + j) * NW;
-#pragma unroll
-            for (int u = 0; u < 2; ++u) {
-              const int q = q0 + 64 * u;
-              if (q < DAP) Da[ml * DAP + q] = val[j][u];
-            }
-          }
-        }
-      }
-    }
-    // ---- stage input window: Bx[c_local][r] ----
-    {
-      constexpr int RPW = CB / NW;        // 8, 16 or 32
-      constexpr int RG = 8;
-      const int g0 = f0 * V;
-      for (int jg = 0; jg < RPW; jg += RG) {
-        for (int r0 = lane; r0 < WLP; r0 += 128) {
-          float val[RG][2];
-#pragma unroll
-          for (int j = 0; j < RG; ++j) {
-            const int cl = wave + (jg + j) * NW;
-            const int c = c0 + cl;
-            const bool okr = c < a.C;
-            const float* src = a.in + ((long)n * a.C + (okr ? c : 0)) * Psrc;
-#pragma unroll
-            for (int u = 0; u < 2; ++u) {
-              const int r = r0 + 64 * u;
-              const int gp = g0 + r;
-              const bool ok = okr && r < WL && gp >= 0 && gp < Psrc;
-              const float t = src[ok ? gp : 0];
-              val[j][u] = ok ? t : 0.f;
-            }
-          }
-#pragma unroll
-          for (int j = 0; j < RG; ++j) {
-            const int cl = wave + (jg + j) * NW;
-#pragma unroll
-            for (int u = 0; u < 2; ++u) {
-              const int r = r0 + 64 * u;
-              if (r < WLP) Bx[cl * WLP + r] = val[j][u];
-            }
-          }
-        }
-      }
-    }
+    __syncthreads();                          // all waves are done with the previous pair's LDS tiles
+    commit_lds(p);
+    const int n = p / a.ntiles;
     if (AGG && n != last_n) {
       const int VP = 2 * ((V + 1) / 2);
       const float* adjn = a.adj + (long)n * 3 * V * V;
       for (int e = tid; e < 3 * VP * 32; e += NT) {
         const int i = e / (VP * 32), r = e - i * (VP * 32);
         const int u = r >> 5, col = r & 31;
-        adjp[e] = (u < V && col < V) ? adjn[(i * V + u) * V + col] : 0.f;
+        const bool ok = u < V && col < V;
+        const float t = adjn[ok ? ((i * V + u) * V + col) : 0];
+        adjp[e] = ok ? t : 0.f;
       }
       last_n = n;
     }
+    if (p + 1 < p_end) issue_loads(p + 1);    // in flight during this pair's matrix-core loop
     __syncthreads();
 #pragma unroll
     for (int sub = 0; sub < NSUB; ++sub) {
@@ -189,42 +197,36 @@ __global__ void __launch_bounds__(MW* CW * 64) conv_wgrad_kernel(const WgradArgs
         }
         __syncthreads();
       }
-      const float* Bsrc = AGG ? Bg : Bx;
-      const int BP = AGG ? GP : WLP;
-      for (int s = 0; s < KS; ++s) {
+      const float* Bsrc = (AGG ? Bg : Bx) + (cw * 32 + lr) * (AGG ? GP : WLP) + tap0 * V;
+      const float* Asrc = Da + (mw * 32 + lr) * DAP;
+      for (int s = s_begin; s < s_end; ++s) {
         const int q = 2 * s + h;
         const int qo = qoff[q];
-        float av[TMr], bv[TNr][TAPS];
+        const float av = Asrc[q];
+        float bv[NTW];
 #pragma unroll
-        for (int x = 0; x < TMr; ++x) av[x] = Da[((mw * TMr + x) * 32 + lr) * DAP + q];
+        for (int t = 0; t < NTW; ++t) bv[t] = Bsrc[qo + ((TSPLIT && t >= ntaps) ? 0 : t * V)];
 #pragma unroll
-        for (int y = 0; y < TNr; ++y)
-#pragma unroll
-          for (int tap = 0; tap < TAPS; ++tap) bv[y][tap] = Bsrc[((cw * TNr + y) * 32 + lr) * BP + qo + tap * V];
-#pragma unroll
-        for (int x = 0; x < TMr; ++x)
-#pragma unroll
-          for (int y = 0; y < TNr; ++y)
-#pragma unroll
-            for (int tap = 0; tap < TAPS; ++tap)
-              acc[x][y][sub * TAPS + tap] = mfma32(av[x], bv[y][tap], acc[x][y][sub * TAPS + tap]);
+        for (int t = 0; t < NTW; ++t)
+          if (!TSPLIT || t < ntaps) acc[sub * NTW + t] = mfma32(av, bv[t], acc[sub * NTW + t]);
       }
     }
   }
-  // ---- write the partial slab in the final weight layout ----
-  float* dst = a.part + (long)blockIdx.y * a.wsize;
+  // ---- write this wave group's partial slab in the final weight layout ----
+  const int slab = KSPLIT ? ((int)blockIdx.y * TH + th) : (int)blockIdx.y;
+  float* dst = a.part + (long)slab * a.wsize;
 #pragma unroll
-  for (int x = 0; x < TMr; ++x)
+  for (int z = 0; z < NACC; ++z) {
+    const int sub = z / NTW, t = z - sub * NTW;
+    if (TSPLIT && t >= ntaps) continue;
+    const int zz = AGG ? sub : (tap0 + t);
 #pragma unroll
-    for (int y = 0; y < TNr; ++y)
-#pragma unroll
-      for (int z = 0; z < NSUB * TAPS; ++z)
-#pragma unroll
-        for (int j = 0; j < 16; ++j) {
-          const int m = m0 + (mw * TMr + x) * 32 + mfma_row(j, h);
-          const int c = c0 + (cw * TNr + y) * 32 + lr;
-          if (m < a.M && c < a.C) dst[(long)m * a.so_m + (long)z * a.so_t + (long)c * a.so_c] = acc[x][y][z][j];
-        }
+    for (int j = 0; j < 16; ++j) {
+      const int m = m0 + mw * 32 + mfma_row(j, h);
+      const int c = c0 + cw * 32 + lr;
+      if (m < a.M && c < a.C) dst[(long)m * a.so_m + (long)zz * a.so_t + (long)c * a.so_c] = acc[z][j];
+    }
+  }
 }
 
 __global__ void wgrad_reduce_kernel(const float* __restrict__ part, float* __restrict__ dw, long wsize, int nsplit) {
@@ -236,14 +238,14 @@ __global__ void wgrad_reduce_kernel(const float* __restrict__ part, float* __res
 }
 
 struct WGeom {
-  int tt, ntiles, FW, WLP, DAP, GP, nsplit, pairs_per_split, grid_x;
+  int tt, ntiles, FW, WLP, DAP, GP, nsplit, nslabs, pairs_per_split, grid_x;
   int off_bx, off_bg, off_adj, off_qoff;
   size_t smem_bytes;
 };
 
-template <int TAPS, int AGG, int MW, int CW, int TMr, int TNr>
+template <int TAPS, int AGG, int MW, int CW, int TH, bool KSPLIT>
 WGeom wgeom(int N, int M, int C, int V, int T_out, int stride) {
-  constexpr int BM = MW * TMr * 32, CB = CW * TNr * 32;
+  constexpr int BM = MW * 32, CB = CW * 32;
   WGeom g;
   g.tt = 128 / V;
   if (g.tt > T_out) g.tt = T_out;
@@ -268,24 +270,26 @@ WGeom wgeom(int N, int M, int C, int V, int T_out, int stride) {
   const int nmb = (M + BM - 1) / BM, ncb = (C + CB - 1) / CB;
   g.grid_x = nmb * ncb;
   const int pairs = N * g.ntiles;
-  int want = 512 / g.grid_x;
+  int want = 256 / g.grid_x;            // one 8-wave workgroup per CU
   if (want < 1) want = 1;
   if (want > pairs) want = pairs;
   g.pairs_per_split = (pairs + want - 1) / want;
   g.nsplit = (pairs + g.pairs_per_split - 1) / g.pairs_per_split;
+  g.nslabs = g.nsplit * (KSPLIT ? TH : 1);
   return g;
 }
 
-template <int TAPS, int AGG, int MW, int CW, int TMr, int TNr>
+template <int TAPS, int AGG, int MW, int CW, int TH, bool KSPLIT, int WBX>
 int launch_wgrad(WgradArgs a, float* dw, void* ws, size_t ws_bytes, hipStream_t stream) {
-  const WGeom g = wgeom<TAPS, AGG, MW, CW, TMr, TNr>(a.N, a.M, a.C, a.V, a.T_out, a.stride);
+  const WGeom g = wgeom<TAPS, AGG, MW, CW, TH, KSPLIT>(a.N, a.M, a.C, a.V, a.T_out, a.stride);
   if (g.smem_bytes > 160 * 1024) return AGCN_ERR_UNSUPPORTED;
-  if ((size_t)g.nsplit * a.wsize * 4 > ws_bytes) return AGCN_ERR_WORKSPACE;
+  if (g.WLP > WBX * 64 || g.tt * a.V > 128) return AGCN_ERR_UNSUPPORTED;
+  if ((size_t)g.nslabs * a.wsize * 4 > ws_bytes) return AGCN_ERR_WORKSPACE;
   a.part = (float*)ws;
   a.tt = g.tt; a.ntiles = g.ntiles; a.FW = g.FW; a.WLP = g.WLP; a.DAP = g.DAP; a.GP = g.GP;
   a.nsplit = g.nsplit; a.pairs_per_split = g.pairs_per_split;
   a.off_bx = g.off_bx; a.off_bg = g.off_bg; a.off_adj = g.off_adj; a.off_qoff = g.off_qoff;
-  auto kern = conv_wgrad_kernel<TAPS, AGG, MW, CW, TMr, TNr>;
+  auto kern = conv_wgrad_kernel<TAPS, AGG, MW, CW, TH, KSPLIT, WBX>;
   static bool attr_set = false;
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
@@ -293,36 +297,36 @@ int launch_wgrad(WgradArgs a, float* dw, void* ws, size_t ws_bytes, hipStream_t 
     if (e != hipSuccess) return (int)e;
     attr_set = true;
   }
-  hipLaunchKernelGGL(kern, dim3(g.grid_x, g.nsplit), dim3(MW * CW * 64), g.smem_bytes, stream, a);
+  hipLaunchKernelGGL(kern, dim3(g.grid_x, g.nsplit), dim3(512), g.smem_bytes, stream, a);
   int rc = agcn_check_launch();
   if (rc) return rc;
   const int threads = 256;
   hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((a.wsize + threads - 1) / threads)), dim3(threads), 0,
-                     stream, (const float*)ws, dw, a.wsize, g.nsplit);
+                     stream, (const float*)ws, dw, a.wsize, g.nslabs);
   return agcn_check_launch();
 }
 
-template <int TAPS, int AGG, int MW, int CW, int TMr, int TNr>
+template <int TAPS, int AGG, int MW, int CW, int TH, bool KSPLIT>
 size_t ws_wgrad(int N, int M, int C, int V, int T_out, int stride, long wsize) {
-  const WGeom g = wgeom<TAPS, AGG, MW, CW, TMr, TNr>(N, M, C, V, T_out, stride);
-  return (size_t)g.nsplit * wsize * 4;
+  const WGeom g = wgeom<TAPS, AGG, MW, CW, TH, KSPLIT>(N, M, C, V, T_out, stride);
+  return (size_t)g.nslabs * wsize * 4;
 }
 
 }  // namespace
 
 extern "C" {
 
-// bytes of workspace agcn_conv_bwd_weight / agcn_gcn_project_bwd_weight need (upper bound over configs)
+// bytes of workspace agcn_conv_bwd_weight / agcn_gcn_project_bwd_weight need
 size_t agcn_conv_bwd_weight_workspace(int N, int Cin, int Cout, int T, int V, int taps, int stride) {
   const int pad = (taps - 1) / 2;
   const int T_out = (T + 2 * pad - taps) / stride + 1;
   const long wsize = (long)Cout * Cin * taps;
   if (taps == 9) {
-    if (Cout % 128 == 0) return ws_wgrad<9, 0, 4, 1, 1, 1>(N, Cout, Cin, V, T_out, stride, wsize);
-    return ws_wgrad<9, 0, 2, 2, 1, 1>(N, Cout, Cin, V, T_out, stride, wsize);
+    if (Cout % 128 == 0) return ws_wgrad<9, 0, 4, 1, 2, false>(N, Cout, Cin, V, T_out, stride, wsize);
+    return ws_wgrad<9, 0, 2, 2, 2, false>(N, Cout, Cin, V, T_out, stride, wsize);
   }
-  if (Cout % 128 == 0) return ws_wgrad<1, 0, 4, 1, 1, 2>(N, Cout, Cin, V, T_out, stride, wsize);
-  return ws_wgrad<1, 0, 2, 2, 1, 1>(N, Cout, Cin, V, T_out, stride, wsize);
+  if (Cout % 128 == 0) return ws_wgrad<1, 0, 4, 2, 1, false>(N, Cout, Cin, V, T_out, stride, wsize);
+  return ws_wgrad<1, 0, 2, 2, 2, true>(N, Cout, Cin, V, T_out, stride, wsize);
 }
 
 // dw[o][c][k] = sum_{n,t,v} dy[n][o][t,v] * x[n][c][(t*stride + k - pad), v]
@@ -338,17 +342,21 @@ int agcn_conv_bwd_weight(const float* dy, const float* x, float* dw, void* works
   a.so_m = (long)Cin * taps; a.so_t = 1; a.so_c = taps; a.wsize = (long)Cout * Cin * taps;
   hipStream_t s = (hipStream_t)stream;
   if (taps == 9) {
-    if (Cout % 128 == 0) return launch_wgrad<9, 0, 4, 1, 1, 1>(a, dw, workspace, workspace_bytes, s);
-    return launch_wgrad<9, 0, 2, 2, 1, 1>(a, dw, workspace, workspace_bytes, s);
+    if (stride == 1) {
+      if (Cout % 128 == 0) return launch_wgrad<9, 0, 4, 1, 2, false, 6>(a, dw, workspace, workspace_bytes, s);
+      return launch_wgrad<9, 0, 2, 2, 2, false, 6>(a, dw, workspace, workspace_bytes, s);
+    }
+    if (Cout % 128 == 0) return launch_wgrad<9, 0, 4, 1, 2, false, 7>(a, dw, workspace, workspace_bytes, s);
+    return launch_wgrad<9, 0, 2, 2, 2, false, 7>(a, dw, workspace, workspace_bytes, s);
   }
-  if (Cout % 128 == 0) return launch_wgrad<1, 0, 4, 1, 1, 2>(a, dw, workspace, workspace_bytes, s);
-  return launch_wgrad<1, 0, 2, 2, 1, 1>(a, dw, workspace, workspace_bytes, s);
+  if (Cout % 128 == 0) return launch_wgrad<1, 0, 4, 2, 1, false, 4>(a, dw, workspace, workspace_bytes, s);
+  return launch_wgrad<1, 0, 2, 2, 2, true, 4>(a, dw, workspace, workspace_bytes, s);
 }
 
 size_t agcn_gcn_project_bwd_weight_workspace(int N, int C, int Cout, int T, int V) {
   const long wsize = 3L * Cout * C;
-  if (Cout % 128 == 0) return ws_wgrad<1, 1, 4, 1, 1, 2>(N, Cout, C, V, T, 1, wsize);
-  return ws_wgrad<1, 1, 2, 2, 1, 1>(N, Cout, C, V, T, 1, wsize);
+  if (Cout % 128 == 0) return ws_wgrad<1, 1, 4, 2, 1, false>(N, Cout, C, V, T, 1, wsize);
+  return ws_wgrad<1, 1, 2, 2, 2, true>(N, Cout, C, V, T, 1, wsize);
 }
 
 // dwcat[o][i*C+c] = sum_{n,t,v} dy[n][o][t,v] * sum_u x[n][c][t,u] adj[n][i][u][v]
@@ -360,8 +368,8 @@ int agcn_gcn_project_bwd_weight(const float* dy, const float* x, const float* ad
   a.dy = dy; a.in = x; a.adj = adj; a.N = N; a.M = Cout; a.C = C; a.V = V; a.T_src = T; a.T_out = T; a.stride = 1;
   a.so_m = 3L * C; a.so_t = C; a.so_c = 1; a.wsize = 3L * Cout * C;
   hipStream_t s = (hipStream_t)stream;
-  if (Cout % 128 == 0) return launch_wgrad<1, 1, 4, 1, 1, 2>(a, dwcat, workspace, workspace_bytes, s);
-  return launch_wgrad<1, 1, 2, 2, 1, 1>(a, dwcat, workspace, workspace_bytes, s);
+  if (Cout % 128 == 0) return launch_wgrad<1, 1, 4, 2, 1, false, 2>(a, dwcat, workspace, workspace_bytes, s);
+  return launch_wgrad<1, 1, 2, 2, 2, true, 2>(a, dwcat, workspace, workspace_bytes, s);
 }
 
 }  // extern "C"
