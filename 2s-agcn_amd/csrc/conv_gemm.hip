@@ -43,7 +43,7 @@ struct ConvGemmArgs {
   int FW, WLP;
   int accumulate;
   int C;                             // DADJ: channels of x
-  int nchunks;
+  int nchunks, nmb;
   int off_bx, off_bg, off_adj;       // LDS offsets (floats)
 };
 
@@ -75,7 +75,7 @@ __global__ void __launch_bounds__(256) pack_weights_kernel(const PackArgs p) {
 
 // WB = max number of 64-float column blocks of a staged window row (compile-time bound of the prefetch registers)
 template <int TAPS, int AGG, int WM, int WN, int TM, int TN, int CK, int WB, int EPI>
-__global__ void __launch_bounds__(WM* WN * 64) conv_gemm_kernel(const ConvGemmArgs a) {
+__global__ void __launch_bounds__(WM* WN * 64, (WM * WN == 8 && TAPS == 1) ? 4 : 2) conv_gemm_kernel(const ConvGemmArgs a) {
   constexpr int NW = WM * WN, NT = NW * 64;
   constexpr int BM = WM * TM * 32;
   constexpr int NSUB = AGG ? 3 : 1;
@@ -94,9 +94,13 @@ __global__ void __launch_bounds__(WM* WN * 64) conv_gemm_kernel(const ConvGemmAr
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int lr = lane & 31, h = lane >> 5;
   const int wm = wave / WN, wn = wave - wm * WN;
+  // 1-D grid: the row blocks of one (sample, frame tile) are adjacent (they stage the same source window, so
+  // it is served from the XCD's L2), and xcd_remap keeps neighbouring tiles on one XCD
   const int bid = xcd_remap(blockIdx.x, gridDim.x);
-  const int n = bid / a.ntiles, tile = bid - n * a.ntiles;
-  const int m0 = blockIdx.y * BM;
+  const int mbk = bid % a.nmb;
+  const int nt_id = bid / a.nmb;
+  const int n = nt_id / a.ntiles, tile = nt_id - n * a.ntiles;
+  const int m0 = mbk * BM;
   const int V = a.V, tt = a.tt, t0 = tile * tt;
   const int ttv = tt * V;
   const int tvalid = min(tt, a.T_out - t0);
@@ -142,7 +146,7 @@ __global__ void __launch_bounds__(WM* WN * 64) conv_gemm_kernel(const ConvGemmAr
   // ---- prefetch registers ----
   f32x4 ra[EA];
   float rb[RPW][WB];
-  const f32x4* wp4 = reinterpret_cast<const f32x4*>(a.wp) + (long)blockIdx.y * a.nchunks * N4;
+  const f32x4* wp4 = reinterpret_cast<const f32x4*>(a.wp) + (long)mbk * a.nchunks * N4;
   const int g0 = f0 * V;
 
   // NOTE: the loaded values are kept RAW in registers; range predicates are re-evaluated at commit time, so
@@ -418,7 +422,7 @@ __global__ void __launch_bounds__(WM* WN * 64) conv_gemm_kernel(const ConvGemmAr
         if (u < V && lr < V) red2[wave * VV + u * V + lr] = d[j];
       }
       __syncthreads();
-      const int slot = tile * nmb + ((C >= BM) ? ((int)blockIdx.y - i * nmb) : 0);
+      const int slot = tile * nmb + ((C >= BM) ? (mbk - i * nmb) : 0);
       float* dst = a.dadj + (((long)n * 3 + i) * ((long)a.ntiles * nmb) + slot) * VV;
       for (int e = tid; e < VV; e += NT) {
         float s = 0.f;
@@ -483,7 +487,7 @@ int launch_cfg(Problem& p, hipStream_t stream) {
   if (g.smem_bytes > 160 * 1024) return AGCN_ERR_UNSUPPORTED;
   if (g.FW * a.V > WB * 64) return AGCN_ERR_UNSUPPORTED;
   if (g.pack_floats * 4 > p.ws_bytes) return AGCN_ERR_WORKSPACE;
-  a.tt = g.tt; a.ntiles = g.ntiles; a.FW = g.FW; a.WLP = g.WLP; a.nchunks = g.nchunks;
+  a.tt = g.tt; a.ntiles = g.ntiles; a.FW = g.FW; a.WLP = g.WLP; a.nchunks = g.nchunks; a.nmb = g.nmb;
   a.off_bx = g.off_bx; a.off_bg = g.off_bg; a.off_adj = g.off_adj;
   a.wp = (const float*)p.ws;
   if (g.nchunks > 0) {
@@ -503,7 +507,7 @@ int launch_cfg(Problem& p, hipStream_t stream) {
     if (e != hipSuccess) return (int)e;
     attr_set = true;
   }
-  dim3 grid((unsigned)(a.N * g.ntiles), (unsigned)g.nmb);
+  dim3 grid((unsigned)(a.N * g.ntiles * g.nmb));
   hipLaunchKernelGGL(kern, grid, dim3(WM * WN * 64), g.smem_bytes, stream, a);
   return agcn_check_launch();
 }
@@ -521,7 +525,7 @@ size_t pack_bytes(int V, int T_out, int src_stride, int M, int Kinner) {
   (((M) % 128 == 0) ? pack_bytes<TAPS, AGG, 2, 4, 2, 2, CK128, 0>(V, T, ss, M, K)            \
                     : pack_bytes<TAPS, AGG, 1, 4, 2, 2, CK64, 0>(V, T, ss, M, K))
 
-constexpr int CK9 = 8, CK1 = 16, CKA = 8, CKD = 32;
+constexpr int CK9 = 8, CK1 = 32, CKA = 8, CKD = 32;
 
 }  // namespace
 
@@ -585,6 +589,7 @@ int agcn_conv_fwd(const float* x, const float* w, const float* bias, float* y, f
   p.ws = workspace; p.ws_bytes = workspace_bytes;
   hipStream_t s = (hipStream_t)stream;
   if (taps == 9) return DISPATCH_BM(9, 0, CK9, CK9, 11, p, s);
+  if (stride == 1) return DISPATCH_BM(1, 0, CK1, CK1, 4, p, s);
   return DISPATCH_BM(1, 0, CK1, CK1, 8, p, s);
 }
 
@@ -611,7 +616,7 @@ int agcn_conv_bwd_data(const float* dy, const float* w, float* dx, int accumulat
     a.T_out = T; a.out_fs = 1; a.out_fo = 0; a.f_off = -pad;
     p.tap_mul = 1; p.tap_add = 0; p.tap_flip_from = taps - 1;
     if (taps == 9) return DISPATCH_BM(9, 0, CK9, CK9, 8, p, s);
-    return DISPATCH_BM(1, 0, CK1, CK1, 8, p, s);
+    return DISPATCH_BM(1, 0, CK1, CK1, 4, p, s);
   }
   // stride 2: output frames of parity `par` form a stride-1 problem over tau (t = 2*tau + par):
   //   dx[2tau+par] = sum_j W[k = taps-1-(2j+par')] dy[tau + j + off]   with only the taps of matching parity
@@ -630,10 +635,10 @@ int agcn_conv_bwd_data(const float* dy, const float* w, float* dx, int accumulat
   // 1x1 stride 2: even t takes dy[t/2]; odd t receives no signal (zero + addends)
   a.T_out = (T + 1) / 2; a.out_fs = 2; a.out_fo = 0; a.f_off = 0;
   p.tap_mul = 1; p.tap_add = 0; p.tap_flip_from = 0;
-  rc = DISPATCH_BM(1, 0, CK1, CK1, 8, p, s);
+  rc = DISPATCH_BM(1, 0, CK1, CK1, 4, p, s);
   if (rc) return rc;
   a.T_out = T / 2; a.out_fo = 1; a.Kinner = 0;      // no K chunks: the epilogue writes 0 (+accumulate/addends)
-  if (a.T_out > 0) rc = DISPATCH_BM(1, 0, CK1, CK1, 8, p, s);
+  if (a.T_out > 0) rc = DISPATCH_BM(1, 0, CK1, CK1, 4, p, s);
   return rc;
 }
 
