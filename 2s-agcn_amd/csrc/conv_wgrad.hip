@@ -212,7 +212,8 @@ __global__ void __launch_bounds__(512) conv_wgrad_kernel(const WgradArgs a) {
       }
     }
   }
-  // ---- write this wave group's partial slab in the final weight layout ----
+  // ---- write this wave group's partial slab as [z][m][c] (lanes = consecutive c: coalesced 128-byte rows; the
+  //      reduce kernel transposes into the weight layout) ----
   const int slab = KSPLIT ? ((int)blockIdx.y * TH + th) : (int)blockIdx.y;
   float* dst = a.part + (long)slab * a.wsize;
 #pragma unroll
@@ -224,17 +225,23 @@ __global__ void __launch_bounds__(512) conv_wgrad_kernel(const WgradArgs a) {
     for (int j = 0; j < 16; ++j) {
       const int m = m0 + mw * 32 + mfma_row(j, h);
       const int c = c0 + cw * 32 + lr;
-      if (m < a.M && c < a.C) dst[(long)m * a.so_m + (long)zz * a.so_t + (long)c * a.so_c] = acc[z][j];
+      if (m < a.M && c < a.C) dst[((long)zz * a.M + m) * a.C + c] = acc[z][j];
     }
   }
 }
 
-__global__ void wgrad_reduce_kernel(const float* __restrict__ part, float* __restrict__ dw, long wsize, int nsplit) {
+// dw[m*so_m + z*so_t + c*so_c] = sum_k part[k][z][m][c]   (fixed order)
+__global__ void wgrad_reduce_kernel(const float* __restrict__ part, float* __restrict__ dw, long wsize, int nsplit,
+                                    int M, int C, long so_m, long so_t, long so_c) {
   const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= wsize) return;
   float s = 0.f;
   for (int k = 0; k < nsplit; ++k) s += part[(long)k * wsize + i];
-  dw[i] = s;
+  const int c = (int)(i % C);
+  const long r = i / C;
+  const int m = (int)(r % M);
+  const int z = (int)(r / M);
+  dw[(long)m * so_m + (long)z * so_t + (long)c * so_c] = s;
 }
 
 struct WGeom {
@@ -302,7 +309,7 @@ int launch_wgrad(WgradArgs a, float* dw, void* ws, size_t ws_bytes, hipStream_t 
   if (rc) return rc;
   const int threads = 256;
   hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((a.wsize + threads - 1) / threads)), dim3(threads), 0,
-                     stream, (const float*)ws, dw, a.wsize, g.nslabs);
+                     stream, (const float*)ws, dw, a.wsize, g.nslabs, a.M, a.C, a.so_m, a.so_t, a.so_c);
   return agcn_check_launch();
 }
 

@@ -45,31 +45,44 @@ def randomize_like_training(model, seed):
 
 
 def dominant_kernel_roofline(device, reps=10):
-    """Time the dominant kernel of the step (unit_tcn 9x1 weight-gradient contraction at the l2-l4 shape,
-    N'=128, C=64, T=300, V=25) with HIP events on the stream it is launched on."""
+    """The kernel with the largest share of the step (profiles/r01_*_kernel_stats.txt): conv_gemm_kernel<9,...> =
+    unit_tcn's 9x1 temporal convolution forward at the l9/l10 shape (N'=128, C=Cout=256, T=75, V=25), timed with
+    HIP events on the stream it is launched on.  Algorithmic work per launch: 2*Cout*Cin*9 FLOP per
+    output position x 128*75*25 positions = 283.1 GFLOP; bound = fp32 matrix cores (157.3 TFLOP/s).
+    `traffic` = HBM bytes per launch from the committed PMC passes (tools/pmc_roofline.py + tools/pmc_parse.py)."""
     import agcn_amd  # noqa: F401
     from agcn_amd import ops
-    N, C, T, V = 128, 64, 300, 25
+    N, C, T, V = 128, 256, 75, 25
     g = torch.Generator().manual_seed(0)
     x = torch.randn(N, C, T, V, generator=g).to(device)
-    dy = torch.randn(N, C, T, V, generator=g).to(device)
-    w_shape = (C, C, 9, 1)
+    w = (torch.randn(C, C, 9, 1, generator=g) / 48.0).to(device)
+    b = torch.zeros(C, device=device)
     for _ in range(2):
-        ops.conv_bwd_weight(dy, x, w_shape)
+        ops.conv_fwd(x, w, b, 1, want_stats=True)
     torch.cuda.synchronize()
     s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     s.record()
     for _ in range(reps):
-        ops.conv_bwd_weight(dy, x, w_shape)
+        ops.conv_fwd(x, w, b, 1, want_stats=True)
     e.record()
     torch.cuda.synchronize()
-    ms = s.elapsed_time(e) / reps
-    flops = 2.0 * C * C * 9 * T * V * N          # algorithmic: 2*Cout*Cin*9 per output position
+    ms = s.elapsed_time(e) / reps          # includes the ~3 us weight-pack launch that precedes every call
+    flops = 2.0 * C * C * 9 * T * V * N
     achieved = flops / (ms * 1e-3) / 1e12
-    return {"bound": "mfma", "kernel": "conv_wgrad_kernel<9,0,2,2,1,1> (unit_tcn dW, l2-l4 shape)",
+    traffic = None
+    try:
+        with open(os.path.join(ROOT, 'profiles', 'r01_pmc_traffic.json')) as f:
+            pmc = json.load(f)
+        key = [k for k in pmc if k.startswith('conv_gemm_kernel<9, 0, 2, 4, 2, 2, 8, 11, 0>')]
+        if key:
+            traffic = pmc[key[0]]['hbm_bytes']
+    except (OSError, ValueError):
+        pass
+    return {"bound": "mfma", "kernel": "conv_gemm_kernel<9,0,2,4,2,2,8,11,0> (unit_tcn 9x1 conv forward, l9-l10 shape)",
             "achieved": round(achieved, 2), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-            "frac": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": None,
-            "ms_per_launch": round(ms, 4), "flops_per_launch": flops}
+            "frac": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": traffic,
+            "ms_per_launch": round(ms, 4), "flops_per_launch": flops,
+            "algorithmic_bytes_per_launch": 4.0 * 2 * N * C * T * V}
 
 
 def host_cores():
@@ -81,7 +94,7 @@ def host_cores():
     return max(1, min(n, int(os.environ.get('AGCN_CPU_THREADS', '16'))))
 
 
-def cpu_baseline(batch=2, budget_s=20.0, max_steps=8):
+def cpu_baseline(batch=4, budget_s=15.0, max_steps=40):
     """The CPU oracle (port of reference agcn.py, pinned to reference-generated fixtures) doing the same training step
     on a bounded sample: training steps of `batch` clips for about `budget_s` seconds after one warm-up step."""
     import numpy as np
