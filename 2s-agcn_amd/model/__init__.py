@@ -1,1 +1,1 @@
-from . import agcn  # noqa: F401
+from . import aagcn, agcn  # noqa: F401

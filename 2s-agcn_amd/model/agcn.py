@@ -144,7 +144,7 @@ class unit_gcn(nn.Module):
 
     def forward(self, x):
         _require_gpu(x, 'unit_gcn')
-        y = ops.UnitGCNFunction.apply(x, *self.packed_args(), self.training)
+        y = ops.UnitGCNFunction.apply(x, *self.packed_args(), self.training, None, True)
         self.tick()
         return y
 

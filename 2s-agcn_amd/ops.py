@@ -252,14 +252,19 @@ def _bn_coeffs(training, stats, count, w, b, rm, rv):
     return bn_eval_coeffs(w, b, rm, rv)
 
 
-def gcn_forward(c, x, A, PA, wab, bab, wd, bd, bn, down, training):
-    """unit_gcn.forward (reference agcn.py:92-109).
+def gcn_forward(c, x, A, PA, wab, bab, wd, bd, bn, down, training, alpha=None, adaptive=True):
+    """unit_gcn.forward (reference agcn.py:92-109) and AAGCN's GCNUnit core (aagcn.py:164-177, 264-266).
     wab: (6Ci, C, 1, 1) rows [a0|b0|a1|b1|a2|b2]; wd: (Cout, 3C); bd: summed conv_d biases;
-    bn = (weight, bias, running_mean, running_var); down = None | (w, b, bn_w, bn_b, bn_rm, bn_rv)."""
+    bn = (weight, bias, running_mean, running_var); down = None | (w, b, bn_w, bn_b, bn_rm, bn_rv).
+    AGCN: adj = P + A + PA.  AAGCN: A = None, adj = PA + alpha*P.  adaptive=False (NonAdaptiveGCN): adj = A."""
     N, C, T, V = x.shape
     count = N * T * V
-    tp, _ = conv_fwd(x, wab, bab)
-    P, adj = adjacency_fwd(tp, A, PA)
+    if adaptive:
+        tp, _ = conv_fwd(x, wab, bab)
+        P, adj = adjacency_fwd(tp, A, PA, alpha)
+    else:
+        tp = P = None
+        adj = A.unsqueeze(0).expand(N, 3, V, V).contiguous()
     ypre, st = aggregate_project_fwd(x, adj, wd, bd, want_stats=training)
     bn1 = _bn_coeffs(training, st, count, *bn)
     dpre = bn2 = None
@@ -272,6 +277,7 @@ def gcn_forward(c, x, A, PA, wab, bab, wd, bd, bn, down, training):
     c.g_x, c.g_tp, c.g_P, c.g_adj, c.g_ypre, c.g_dpre, c.g_out = x, tp, P, adj, ypre, dpre, out
     c.g_bn1, c.g_bn2 = bn1, bn2
     c.g_params = (wab, wd, bn[0], down[0] if down is not None else None, down[2] if down is not None else None)
+    c.g_alpha, c.g_adaptive = alpha, adaptive
     return out
 
 
@@ -288,9 +294,12 @@ def gcn_backward(c, dout, extra_add=None, extra_mask=None):
                                         mask2=extra_mask)
     else:
         dx = aggregate_project_bwd_data(dypre, adj, wd, x.shape, add1=extra_add, mask1=extra_mask)
-    dPA, dtp, dbab, _, _ = adjacency_bwd(dypre, wd, x, tp, P)
-    dwab = conv_bwd_weight(dtp, x, wab.shape)
-    conv_bwd_data(dtp, wab, x.shape, out=dx, accumulate=True)
+    dPA = dwab = dbab = dalpha = None
+    if c.g_adaptive:
+        dPA, dtp, dbab, dalpha, _ = adjacency_bwd(dypre, wd, x, tp, P, c.g_alpha)
+        dwab = conv_bwd_weight(dtp, x, wab.shape)
+        conv_bwd_data(dtp, wab, x.shape, out=dx, accumulate=True)
+    c.g_dalpha = dalpha
     dwdown = None
     if dpre is not None:
         dwdown = conv_bwd_weight(ddpre, x, wdown.shape)
@@ -344,14 +353,15 @@ def _need_train(training):
 
 class UnitGCNFunction(torch.autograd.Function):
     """unit_gcn: args (x, A, PA, wab, bab, wd, bd, bn_w, bn_b, bn_rm, bn_rv,
-                       down_w, down_b, dbn_w, dbn_b, dbn_rm, dbn_rv, training)"""
+                       down_w, down_b, dbn_w, dbn_b, dbn_rm, dbn_rv, training, alpha=None, adaptive=True)"""
 
     @staticmethod
     def forward(ctx, x, A, PA, wab, bab, wd, bd, bn_w, bn_b, bn_rm, bn_rv, down_w, down_b, dbn_w, dbn_b, dbn_rm,
-                dbn_rv, training):
+                dbn_rv, training, alpha=None, adaptive=True):
         c = _Ctx()
         down = None if down_w is None else (down_w, down_b, dbn_w, dbn_b, dbn_rm, dbn_rv)
-        out = gcn_forward(c, x.contiguous(), A, PA, wab, bab, wd, bd, (bn_w, bn_b, bn_rm, bn_rv), down, training)
+        out = gcn_forward(c, x.contiguous(), A, PA, wab, bab, wd, bd, (bn_w, bn_b, bn_rm, bn_rv), down, training,
+                          alpha, adaptive)
         ctx.c, ctx.training = c, training
         ctx.has_down = down is not None
         return out
@@ -363,8 +373,12 @@ class UnitGCNFunction(torch.autograd.Function):
         zb = lambda t: torch.zeros(t.shape[0], dtype=torch.float32, device=dout.device)  # noqa: E731
         dbd = zb(dwd)
         dbdown = zb(dwdown) if ctx.has_down else None
+        dalpha = ctx.c.g_dalpha
+        if dalpha is not None:
+            dalpha = dalpha.reshape(1)
         ctx.c = None
-        return (dx, None, dPA, dwab, dbab, dwd, dbd, dg1, db1, None, None, dwdown, dbdown, dg2, db2, None, None, None)
+        return (dx, None, dPA, dwab, dbab, dwd, dbd, dg1, db1, None, None, dwdown, dbdown, dg2, db2, None, None, None,
+                dalpha, None)
 
 
 class UnitTCNFunction(torch.autograd.Function):
@@ -384,6 +398,40 @@ class UnitTCNFunction(torch.autograd.Function):
         dbias = torch.zeros(dw.shape[0], dtype=torch.float32, device=dout.device)
         ctx.c = None
         return dg, dw, dbias, dg1, db1, None, None, None, None
+
+
+class TCNResidualFunction(torch.autograd.Function):
+    """relu(bn(conv9(g)) + residual(x)) as its own autograd node (AAGCN: the attention ops sit between the GCN core and
+    this).  args: g, x, w, b, bn_w, bn_b, bn_rm, bn_rv, res_mode (0 none, 1 identity, 2 conv), rw, rb, rbn_w, rbn_b,
+    rbn_rm, rbn_rv, stride, training"""
+
+    @staticmethod
+    def forward(ctx, g, x, w, b, bn_w, bn_b, bn_rm, bn_rv, res_mode, rw, rb, rbn_w, rbn_b, rbn_rm, rbn_rv, stride,
+                training):
+        c = _Ctx()
+        res = None if res_mode == 0 else ('identity' if res_mode == 1 else (rw, rb, rbn_w, rbn_b, rbn_rm, rbn_rv))
+        x = x.contiguous() if x is not None else None
+        out = tcn_forward(c, g.contiguous(), w, b, (bn_w, bn_b, bn_rm, bn_rv), stride, x, res, True, training)
+        ctx.c, ctx.training, ctx.res_mode, ctx.stride = c, training, res_mode, stride
+        ctx.x_shape = tuple(x.shape) if x is not None else None
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        _need_train(ctx.training)
+        c = ctx.c
+        dout = dout.contiguous()
+        dg, dw, dg1, db1, drpre, dwres, dg2, db2 = tcn_backward(c, dout)
+        dev = dout.device
+        zb = lambda n: torch.zeros(n, dtype=torch.float32, device=dev)  # noqa: E731
+        dx = None
+        if ctx.res_mode == 1:
+            dx = torch.where(c.t_out > 0, dout, torch.zeros_like(dout))
+        elif ctx.res_mode == 2:
+            dx = conv_bwd_data(drpre, c.t_params[2], ctx.x_shape, ctx.stride)
+        ctx.c = None
+        return (dg, dx, dw, zb(dw.shape[0]), dg1, db1, None, None, None,
+                dwres, zb(dwres.shape[0]) if ctx.res_mode == 2 else None, dg2, db2, None, None, None, None)
 
 
 class TCNGCNUnitFunction(torch.autograd.Function):

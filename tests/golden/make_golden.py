@@ -246,7 +246,7 @@ def make_graphs():
     np.savez_compressed(os.path.join(HERE, 'graphs.npz'), **out)
 
 
-if __name__ == '__main__':
+if __name__ == '__main__' and len(sys.argv) == 1:
     torch.manual_seed(0)
     torch.set_num_threads(8)
     ref = load_reference()
@@ -256,3 +256,131 @@ if __name__ == '__main__':
     for case in MODEL_CASES:
         make_model(ref, *case)
     make_train_trace(ref)
+
+
+# ------------------------------------------------------------------------------------------------
+# AAGCN (reference model/architecture/aagcn/aagcn.py).  Run: python tests/golden/make_golden.py aagcn
+# ------------------------------------------------------------------------------------------------
+def load_reference_aagcn():
+    """aagcn.py imports torchinfo (absent) and model.layers.module.ghostbatchnorm: register an empty `torchinfo`
+    stub and load ghostbatchnorm.py by path under its dotted name."""
+    import types
+    sys.path.insert(0, REF)
+    for k in [k for k in sys.modules if k == 'graph' or k.startswith('graph.') or k == 'model' or k.startswith('model.')]:
+        del sys.modules[k]
+    ti = types.ModuleType('torchinfo')
+    ti.summary = lambda *a, **k: None
+    sys.modules['torchinfo'] = ti
+    for name in ('model', 'model.layers', 'model.layers.module'):
+        sys.modules[name] = types.ModuleType(name)
+    spec = importlib.util.spec_from_file_location(
+        'model.layers.module.ghostbatchnorm', os.path.join(REF, 'model/layers/module/ghostbatchnorm.py'))
+    gb = importlib.util.module_from_spec(spec)
+    sys.modules['model.layers.module.ghostbatchnorm'] = gb
+    spec.loader.exec_module(gb)
+    spec = importlib.util.spec_from_file_location('ref_aagcn', os.path.join(REF, 'model/architecture/aagcn/aagcn.py'))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+AAGCN_UNIT_CASES = [
+    # name, cin, cout, stride, residual, T, V, seed, stress, adaptive, attention
+    ('au_64_64_s1_v25', 64, 64, 1, True, 16, 25, 401, 4.0, True, True),
+    ('au_64_128_s2_v25', 64, 128, 2, True, 16, 25, 402, 3.0, True, True),
+    ('au_3_64_s1_v18', 3, 64, 1, False, 16, 18, 403, 1.0, True, True),
+    ('au_64_64_s1_v25_plain', 64, 64, 1, True, 16, 25, 404, 1.0, False, False),
+]
+
+
+def make_aagcn_unit(ref, name, cin, cout, stride, residual, t, v, seed, stress, adaptive, attention):
+    A = ref_graph(v)
+    fn = ref.AdaptiveGCN if adaptive else ref.NonAdaptiveGCN
+    unit = ref.TCNGCNUnit(cin, cout, A, stride=stride, residual=residual, adaptive=fn, attention=attention)
+    shapes = orc.aagcn_unit_param_shapes('', cin, cout, v, stride, residual, adaptive, attention)
+    assert set(shapes) == set(unit.state_dict().keys()), set(shapes) ^ set(unit.state_dict().keys())
+    sd = orc.aagcn_randomized_state(shapes, seed, stress=stress)
+    unit.load_state_dict(sd)
+    xn, rn = unit_inputs(cin, cout, stride, t, v, seed)
+    out = {}
+    unit.eval()
+    with torch.no_grad():
+        out['y_eval'] = unit(torch.from_numpy(xn)).numpy()
+    unit.train()
+    x = torch.from_numpy(xn).requires_grad_(True)
+    y = unit(x)
+    (y * torch.from_numpy(rn)).sum().backward()
+    out['y'] = y.detach().numpy()
+    out['dx'] = x.grad.numpy()
+    pack_grads(out, unit.named_parameters())
+    unit64 = ref.TCNGCNUnit(cin, cout, A, stride=stride, residual=residual, adaptive=fn, attention=attention).double()
+    unit64.load_state_dict({k: v_.double() if v_.is_floating_point() else v_ for k, v_ in sd.items()})
+    for m_ in unit64.modules():
+        if isinstance(m_, ref.NonAdaptiveGCN):
+            m_.A = m_.A.double()
+    unit64.train()
+    x64 = torch.from_numpy(xn).double().requires_grad_(True)
+    (unit64(x64) * torch.from_numpy(rn).double()).sum().backward()
+    out['dx64'] = x64.grad.numpy().astype(np.float32)
+    pack_grads(out, unit64.named_parameters(), prefix='g64.')
+    for k, b in unit.state_dict().items():
+        if k.endswith(('running_mean', 'running_var')):
+            out['buf.' + k] = b.numpy().copy()
+    out['meta'] = np.array([cin, cout, stride, int(residual), t, v, seed, int(adaptive), int(attention)], dtype=np.int64)
+    out['meta.stress'] = np.float32(stress)
+    np.savez_compressed(os.path.join(HERE, name + '.npz'), **out)
+    print(f'{name}: y {out["y"].shape} |y|max {np.abs(out["y"]).max():.3f}')
+
+
+def make_aagcn_model(ref, name='am_ntu_b1_t64', n=1, v=25, num_class=60, seed=501, stress=3.0, t=64):
+    model = ref.Model(num_class=num_class, num_point=v, num_person=2, graph='graph.ntu_rgb_d.Graph',
+                      graph_args=dict(labeling_mode='spatial'))
+    shapes = orc.aagcn_model_param_shapes(num_class, v)
+    assert set(shapes) == set(model.state_dict().keys()), set(shapes) ^ set(model.state_dict().keys())
+    sd = orc.aagcn_randomized_state(shapes, seed, stress=stress)
+    model.load_state_dict(sd)
+    xn, lab = model_inputs(n, v, num_class, seed, t)
+    out = {}
+    model.eval()
+    with torch.no_grad():
+        le, aux = model(torch.from_numpy(xn))
+        assert aux is None
+        out['logits_eval'] = le.numpy()
+    model.train()
+    logits, _ = model(torch.from_numpy(xn))
+    loss = torch.nn.functional.cross_entropy(logits, torch.from_numpy(lab))
+    loss.backward()
+    out['logits'] = logits.detach().numpy()
+    out['loss'] = np.float64(loss.item())
+    pack_grads(out, model.named_parameters(), full_limit=2000)
+    model64 = ref.Model(num_class=num_class, num_point=v, num_person=2, graph='graph.ntu_rgb_d.Graph',
+                        graph_args=dict(labeling_mode='spatial')).double()
+    model64.load_state_dict({k: v_.double() if v_.is_floating_point() else v_ for k, v_ in sd.items()})
+    model64.train()
+    l64, _ = model64(torch.from_numpy(xn).double())
+    torch.nn.functional.cross_entropy(l64, torch.from_numpy(lab)).backward()
+    pack_grads(out, model64.named_parameters(), prefix='g64.', full_limit=2000)
+    g64 = {k: p.grad.detach().clone() for k, p in model64.named_parameters()}
+    sens = {k: 0.0 for k in g64}
+    prng = torch.Generator().manual_seed(seed)
+    for _ in range(3):
+        model64.zero_grad()
+        xp = torch.from_numpy(xn).double()
+        xp = xp * (1.0 + 1e-6 * torch.randn(xp.shape, generator=prng, dtype=torch.float64))
+        torch.nn.functional.cross_entropy(model64(xp)[0], torch.from_numpy(lab)).backward()
+        for k, p in model64.named_parameters():
+            sens[k] = max(sens[k], float((p.grad - g64[k]).abs().max() / max(1e-300, float(g64[k].abs().max()))))
+    for k, v_ in sens.items():
+        out['sens.' + k] = np.float32(v_)
+    out['meta'] = np.array([n, v, num_class, seed, t], dtype=np.int64)
+    out['meta.stress'] = np.float32(stress)
+    np.savez_compressed(os.path.join(HERE, name + '.npz'), **out)
+    print(f'{name}: loss {out["loss"]:.6f}')
+
+
+if __name__ == '__main__' and len(sys.argv) > 1 and sys.argv[1] == 'aagcn':
+    torch.manual_seed(0)
+    ref_a = load_reference_aagcn()
+    for case in AAGCN_UNIT_CASES:
+        make_aagcn_unit(ref_a, *case)
+    make_aagcn_model(ref_a)

@@ -100,3 +100,15 @@ def grad_check(g, gold, name, tol):
         noise = max(noise, float(gold['sens.' + name]), sens_floor(gold))
     err64 = float(np.abs(a - r64).max() / scale)
     return (err32 <= tol) or (err64 <= tol + 3.0 * noise), err32, err64, noise
+
+AAGCN_UNIT_NAMES = ['au_64_64_s1_v25', 'au_64_128_s2_v25', 'au_3_64_s1_v18', 'au_64_64_s1_v25_plain']
+
+
+def is_alias_key(name):
+    """``gcn1.agcn.conv_d.*`` aliases ``gcn1.conv_d.*`` in the reference AAGCN state_dict (aagcn.py:228-233);
+    ``named_parameters()`` reports the tensor under the first name only."""
+    return 'agcn.conv_d.' in name
+
+
+def canonical_key(name):
+    return name.replace('agcn.conv_d.', 'conv_d.')
