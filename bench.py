@@ -25,9 +25,19 @@ import torch.distributed as dist  # noqa: E402
 PEAK_FP32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: exact-f32 matrix rate (v_mfma_f32_32x32x2_f32)
 
 
-def build_model(num_class=60, num_point=25, graph='graph.ntu_rgb_d.Graph'):
+WORKLOADS = {
+    # name: (model module, num_class, num_point, graph, default per-GPU batch, description)
+    'ntu_agcn': ('agcn', 60, 25, 'graph.ntu_rgb_d.Graph', 64, 'AGCN joint-stream NTU-xview shape'),
+    'ntu_aagcn': ('aagcn', 60, 25, 'graph.ntu_rgb_d.Graph', 64, 'AAGCN (attention) NTU-xsub shape, fp32'),
+    'kinetics_agcn': ('agcn', 400, 18, 'graph.kinetics.Graph', 128, 'AGCN Kinetics-Skeleton shape (N,3,300,18,2)'),
+}
+
+
+def build_model(workload='ntu_agcn'):
+    import importlib
     import agcn_amd  # noqa: F401
-    from model.agcn import Model
+    mod, num_class, num_point, graph, _, _ = WORKLOADS[workload]
+    Model = importlib.import_module('model.' + mod).Model
     return Model(num_class=num_class, num_point=num_point, num_person=2, graph=graph,
                  graph_args=dict(labeling_mode='spatial'))
 
@@ -40,8 +50,10 @@ def randomize_like_training(model, seed):
         for name, p in model.named_parameters():
             if name.endswith('gcn1.bn.weight'):
                 p.copy_(torch.rand(p.shape, generator=g) + 0.5)
-            elif name.endswith('.PA'):
+            elif name.endswith('gcn1.PA'):
                 p.copy_(0.05 * torch.randn(p.shape, generator=g))
+            elif name.endswith('agcn.alpha'):
+                p.fill_(0.5)
 
 
 def dominant_kernel_roofline(device, reps=10):
@@ -135,7 +147,9 @@ def main():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=20)
     ap.add_argument('--warmup', type=int, default=5)
-    ap.add_argument('--batch', type=int, default=64, help='per-GPU batch (BASELINE configs[1]: 64)')
+    ap.add_argument('--batch', type=int, default=0, help='per-GPU batch (default: the workload\'s, 64 for configs[1])')
+    ap.add_argument('--workload', default='ntu_agcn', choices=sorted(WORKLOADS),
+                    help='ntu_agcn = BASELINE configs[1]/[2] (the headline); others are the remaining configs')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-roofline', action='store_true')
     args = ap.parse_args()
@@ -154,12 +168,15 @@ def main():
     import agcn_amd  # noqa: F401
     from agcn_amd.trainer import TrainEngine, synthetic_batch
     torch.manual_seed(0)                       # identical initial weights on every rank
-    model = build_model()
+    wl = WORKLOADS[args.workload]
+    if args.batch <= 0:
+        args.batch = wl[4]
+    model = build_model(args.workload)
     randomize_like_training(model, seed=0)
     model.to(device)
     engine = TrainEngine(model, base_lr=0.1, momentum=0.9, nesterov=True, weight_decay=1e-4, max_grad_norm=1.0,
                          world_size=world)
-    data, label = synthetic_batch(args.batch, seed=1234 + rank, device=device)
+    data, label = synthetic_batch(args.batch, num_point=wl[2], num_class=wl[1], seed=1234 + rank, device=device)
 
     def barrier():
         if world > 1:
@@ -185,20 +202,22 @@ def main():
     if rank == 0:
         clips = args.batch * world * args.steps
         out = {
-            "metric": "skeleton-clips/sec fwd+bwd, NTU (N,3,300,25,2)",
+            "metric": "skeleton-clips/sec fwd+bwd, NTU (N,3,300,25,2)" if wl[2] == 25 else
+                      "skeleton-clips/sec fwd+bwd, Kinetics (N,3,300,18,2)",
             "value": round(clips / dt, 2), "unit": "clips/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "AGCN joint-stream NTU-xview shape, full training step "
-                                   "(fwd, CE, bwd, grad all-reduce, clip 1.0, SGD nesterov)",
-                       "per_gpu_batch": args.batch, "global_batch": args.batch * world, "input": "(N,3,300,25,2)",
+            "config": {"workload": wl[5] + ", full training step (fwd, CE, bwd, grad all-reduce, clip 1.0, "
+                                   "SGD nesterov)",
+                       "per_gpu_batch": args.batch, "global_batch": args.batch * world,
+                       "input": f"(N,3,300,{wl[2]},2)",
                        "parallelism": f"dp{world}", "bn": "per-replica"},
             "final_loss": round(final_loss, 5),
         }
-        if world == 1 and not args.no_roofline:
+        if world == 1 and not args.no_roofline and args.workload == 'ntu_agcn':
             out["roofline"] = dominant_kernel_roofline(device)
             print("[bench] roofline done", file=sys.stderr, flush=True)
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and args.workload == 'ntu_agcn':
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out), flush=True)
     if world > 1:
