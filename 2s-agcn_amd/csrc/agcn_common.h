@@ -2,6 +2,8 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -38,6 +40,27 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
 
 extern "C" size_t agcn_colsum_scratch_bytes(int W);
 extern "C" int agcn_colsum(const float* X, int nslots, int W, void* scratch, float* out, void* stream);
+
+// split-bf16 temporal convolution (conv_gemm_bf16.hip); npl: 3 = bf16x6 (fp32-equivalent), 2 = bf16x3
+size_t agcn_bf16_conv_workspace(int Cin, int Cout, int T, int V, int stride);
+int agcn_bf16_conv9_fwd(const float* x, const float* w, const float* bias, float* y, float* stats_part, void* ws,
+                        size_t ws_bytes, int N, int Cin, int Cout, int T, int V, int stride, int npl, hipStream_t s);
+int agcn_bf16_conv9_bwd_data(const float* dy, const float* w, float* dx, int accumulate, const float* add1,
+                             const float* mask1, const float* add2, const float* mask2, void* ws, size_t ws_bytes,
+                             int N, int Cin, int Cout, int T, int V, int stride, int npl, hipStream_t s);
+
+// GEMM arithmetic of the 9x1 temporal convolutions: 0 = f32 MFMA (default), 3 = bf16x6, 2 = bf16x3.
+// Chosen once per process from the environment variable AGCN_GEMM (f32 | bf16x6 | bf16x3).
+static inline int agcn_gemm_precision() {
+  static int mode = -1;
+  if (mode < 0) {
+    const char* e = getenv("AGCN_GEMM");
+    mode = 0;
+    if (e && !strcmp(e, "bf16x6")) mode = 3;
+    else if (e && !strcmp(e, "bf16x3")) mode = 2;
+  }
+  return mode;
+}
 
 static inline int agcn_check_launch() {
   hipError_t e = hipGetLastError();

