@@ -189,6 +189,23 @@ __global__ void __launch_bounds__(WM* WN * 64, (WM * WN == 8 && TAPS == 1) ? 4 :
     }
   };
 
+  // DADJ: the x tile of the epilogue is fetched now (raw, into registers) so its latency hides under the K loop
+  constexpr int XR = (EPI == 1) ? (BM / NW) : 1;
+  float rx[XR][2];
+  if (EPI == 1) {
+#pragma unroll
+    for (int j = 0; j < XR; ++j) {
+      const int m = m0 + wave + j * NW;
+      const bool okr = m < a.M;
+      const float* src = a.xin + ((long)n * a.C + (okr ? (m % a.C) : 0)) * ((long)a.T_full * V) + (long)t0 * V;
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const int q = lane + 64 * u;
+        rx[j][u] = src[(okr && q < nvalid) ? q : 0];
+      }
+    }
+  }
+
   const int nchunks = a.nchunks;
   if (nchunks > 0) issue_loads(0);
   for (int ch = 0; ch < nchunks; ++ch) {
@@ -361,37 +378,14 @@ __global__ void __launch_bounds__(WM* WN * 64, (WM * WN == 8 && TAPS == 1) ? 4 :
           const int q = (wn * TN + tn) * 32 + lr;
           if (q < ttv) Dg[ml * ttv + q] = (q < nvalid && m0 + ml < a.M) ? acc[tm][tn][j] : 0.f;
         }
-    {
-      constexpr int XR = BM / NW;   // rows per wave
-      static_assert(XR % 8 == 0, "x tile rows per wave");
-      for (int jg = 0; jg < XR; jg += 8) {
-        for (int q0 = lane; q0 < ttv; q0 += 128) {
-          float val[8][2];
 #pragma unroll
-          for (int j = 0; j < 8; ++j) {
-            const int ml = wave + (jg + j) * NW;
-            const int m = m0 + ml;
-            const bool okr = m < a.M;
-            const int c = okr ? (m % C) : 0;
-            const float* src = a.xin + ((long)n * C + c) * Pout + (long)t0 * V;
+    for (int j = 0; j < XR; ++j) {
+      const int ml = wave + j * NW;
+      const bool okr = (m0 + ml) < a.M;
 #pragma unroll
-            for (int u = 0; u < 2; ++u) {
-              const int q = q0 + 64 * u;
-              const bool ok = okr && q < nvalid;
-              const float t = src[ok ? q : 0];
-              val[j][u] = ok ? t : 0.f;
-            }
-          }
-#pragma unroll
-          for (int j = 0; j < 8; ++j) {
-            const int ml = wave + (jg + j) * NW;
-#pragma unroll
-            for (int u = 0; u < 2; ++u) {
-              const int q = q0 + 64 * u;
-              if (q < ttv) Xs[ml * ttv + q] = val[j][u];
-            }
-          }
-        }
+      for (int u = 0; u < 2; ++u) {
+        const int q = lane + 64 * u;
+        if (q < ttv) Xs[ml * ttv + q] = (okr && q < nvalid) ? rx[j][u] : 0.f;
       }
     }
     __syncthreads();
@@ -525,7 +519,7 @@ size_t pack_bytes(int V, int T_out, int src_stride, int M, int Kinner) {
   (((M) % 128 == 0) ? pack_bytes<TAPS, AGG, 2, 4, 2, 2, CK128, 0>(V, T, ss, M, K)            \
                     : pack_bytes<TAPS, AGG, 1, 4, 2, 2, CK64, 0>(V, T, ss, M, K))
 
-constexpr int CK9 = 8, CK1 = 32, CKA = 8, CKD = 32;
+constexpr int CK9 = 8, CK1 = 32, CKA = 8, CKD = 64;
 
 }  // namespace
 

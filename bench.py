@@ -23,6 +23,7 @@ import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
 PEAK_FP32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: exact-f32 matrix rate (v_mfma_f32_32x32x2_f32)
+PEAK_BF16_MFMA_TFLOPS = 2500.0     # MI355X_MICROARCH.md: dense bf16 MFMA peak
 
 
 WORKLOADS = {
@@ -57,13 +58,17 @@ def randomize_like_training(model, seed):
 
 
 def dominant_kernel_roofline(device, reps=10):
-    """The kernel with the largest share of the step (profiles/r01_*_kernel_stats.txt): conv_gemm_kernel<9,...> =
-    unit_tcn's 9x1 temporal convolution forward at the l9/l10 shape (N'=128, C=Cout=256, T=75, V=25), timed with
-    HIP events on the stream it is launched on.  Algorithmic work per launch: 2*Cout*Cin*9 FLOP per
-    output position x 128*75*25 positions = 283.1 GFLOP; bound = fp32 matrix cores (157.3 TFLOP/s).
+    """The kernel with the largest share of the step (profiles/r01_*_kernel_stats.txt): unit_tcn's 9x1 temporal
+    convolution forward at the l9/l10 shape (N'=128, C=Cout=256, T=75, V=25), timed with HIP events on the stream it
+    is launched on.  Algorithmic work per launch: 2*Cout*Cin*9 FLOP per output position x 128*75*25
+    positions = 283.1 GFLOP (fp32-equivalent).
+    Default arithmetic (AGCN_GEMM=bf16x6): every fp32 product is 6 bf16 MFMA products with fp32 accumulation, so the
+    binding ceiling is the dense bf16 matrix rate / 6 = 2500/6 = 416.7 TFLOP/s of fp32-equivalent work.
+    AGCN_GEMM=f32: exact-f32 MFMA, ceiling 157.3 TFLOP/s.
     `traffic` = HBM bytes per launch from the committed PMC passes (tools/pmc_roofline.py + tools/pmc_parse.py)."""
     import agcn_amd  # noqa: F401
     from agcn_amd import ops
+    mode = os.environ.get('AGCN_GEMM', 'bf16x6')
     N, C, T, V = 128, 256, 75, 25
     g = torch.Generator().manual_seed(0)
     x = torch.randn(N, C, T, V, generator=g).to(device)
@@ -81,19 +86,25 @@ def dominant_kernel_roofline(device, reps=10):
     ms = s.elapsed_time(e) / reps          # includes the ~3 us weight-pack launch that precedes every call
     flops = 2.0 * C * C * 9 * T * V * N
     achieved = flops / (ms * 1e-3) / 1e12
+    if mode == 'f32':
+        kernel, peak, note = 'conv_gemm_kernel<9,0,2,4,2,2,8,11,0>', PEAK_FP32_MFMA_TFLOPS, 'f32 MFMA'
+    else:
+        products = 3 if mode == 'bf16x3' else 6
+        kernel = 'conv_gemm_bf16_kernel<9,%d,2,4>' % (2 if mode == 'bf16x3' else 3)
+        peak = round(PEAK_BF16_MFMA_TFLOPS / products, 1)
+        note = f'{products} bf16 MFMA products per fp32 product: peak = {PEAK_BF16_MFMA_TFLOPS:.0f}/{products}'
     traffic = None
     try:
         with open(os.path.join(ROOT, 'profiles', 'r01_pmc_traffic.json')) as f:
             pmc = json.load(f)
-        key = [k for k in pmc if k.startswith('conv_gemm_kernel<9, 0, 2, 4, 2, 2, 8, 11, 0>')]
+        key = [k for k in pmc if k.startswith(kernel.replace(',', ', '))]
         if key:
             traffic = pmc[key[0]]['hbm_bytes']
     except (OSError, ValueError):
         pass
-    return {"bound": "mfma", "kernel": "conv_gemm_kernel<9,0,2,4,2,2,8,11,0> (unit_tcn 9x1 conv forward, l9-l10 shape)",
-            "achieved": round(achieved, 2), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-            "frac": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": traffic,
-            "ms_per_launch": round(ms, 4), "flops_per_launch": flops,
+    return {"bound": "mfma", "kernel": kernel + " (unit_tcn 9x1 conv forward, l9-l10 shape)", "arithmetic": note,
+            "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(achieved / peak, 4),
+            "traffic": traffic, "ms_per_launch": round(ms, 4), "flops_per_launch": flops,
             "algorithmic_bytes_per_launch": 4.0 * 2 * N * C * T * V}
 
 
@@ -211,7 +222,9 @@ def main():
                                    "SGD nesterov)",
                        "per_gpu_batch": args.batch, "global_batch": args.batch * world,
                        "input": f"(N,3,300,{wl[2]},2)",
-                       "parallelism": f"dp{world}", "bn": "per-replica"},
+                       "parallelism": f"dp{world}", "bn": "per-replica",
+                       "tcn_gemm": os.environ.get('AGCN_GEMM', 'bf16x6') +
+                                   " (9x1 conv fwd/bwd-data; bf16x6 = fp32-equivalent split, fp32 accumulate)"},
             "final_loss": round(final_loss, 5),
         }
         if world == 1 and not args.no_roofline and args.workload == 'ntu_agcn':
