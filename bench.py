@@ -170,11 +170,17 @@ def main():
     world = int(os.environ.get('WORLD_SIZE', '1'))
     if args.gpus > 1 and world == 1:
         raise SystemExit("bench.py --gpus N>1 must be launched with torch.distributed.run (one process per GPU)")
+    if os.environ.get('AGCN_SINGLE_GPU_RANKS'):      # test hook: all ranks on cuda:0
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     device = torch.device('cuda', local_rank)
     if world > 1:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        dist.init_process_group(backend='nccl', device_id=device)
+        backend = os.environ.get('AGCN_DIST_BACKEND', 'nccl')     # 'gloo' lets two ranks share one GPU in tests
+        if backend == 'nccl':
+            dist.init_process_group(backend='nccl', device_id=device)
+        else:
+            dist.init_process_group(backend=backend)
 
     import agcn_amd  # noqa: F401
     from agcn_amd.trainer import TrainEngine, synthetic_batch
