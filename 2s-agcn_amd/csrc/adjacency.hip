@@ -79,7 +79,7 @@ scores_fwd_kernel(const float* __restrict__ tp, float* __restrict__ spart, int N
 }
 
 // one 64-lane wave per (n, i): sum the partial tiles, scale, column softmax, add the static graph terms
-__global__ void __launch_bounds__(64)
+__global__ void __launch_bounds__(256)
 adj_finalize_kernel(const float* __restrict__ spart, const float* __restrict__ A, const float* __restrict__ PA,
                     const float* __restrict__ alpha, float* __restrict__ Pout, float* __restrict__ adj, int V,
                     int ntiles, float inv_k) {
@@ -87,9 +87,10 @@ adj_finalize_kernel(const float* __restrict__ spart, const float* __restrict__ A
   const int ni = blockIdx.x, i = ni % 3;
   const int VV = V * V, lane = threadIdx.x;
   const float* src = spart + (long)ni * ntiles * VV;
-  for (int e = lane; e < VV; e += 64) {
+  for (int e = lane; e < VV; e += 256) {
     float s = 0.f;
-    for (int t = 0; t < ntiles; ++t) s += src[(long)t * VV + e];
+#pragma unroll 8
+    for (int t = 0; t < ntiles; ++t) s += src[(long)t * VV + e];     // fixed order; 8 loads in flight
     S[e] = s * inv_k;
   }
   __syncthreads();
@@ -116,7 +117,7 @@ adj_finalize_kernel(const float* __restrict__ spart, const float* __restrict__ A
 }
 
 // per (n,i): dadj = sum of slot partials; dS = P * (dP - sum_u P dP) / K with dP = alpha*dadj
-__global__ void __launch_bounds__(64)
+__global__ void __launch_bounds__(256)
 adj_bwd_kernel(const float* __restrict__ dpart, const float* __restrict__ P, const float* __restrict__ alpha,
                float* __restrict__ dadj, float* __restrict__ dS, float* __restrict__ dalpha_part, int V, int nslots,
                float inv_k) {
@@ -125,9 +126,10 @@ adj_bwd_kernel(const float* __restrict__ dpart, const float* __restrict__ P, con
   const int ni = blockIdx.x;
   const int VV = V * V, lane = threadIdx.x;
   const float* src = dpart + (long)ni * nslots * VV;
-  for (int e = lane; e < VV; e += 64) {
+  for (int e = lane; e < VV; e += 256) {
     float s = 0.f;
-    for (int t = 0; t < nslots; ++t) s += src[(long)t * VV + e];
+#pragma unroll 8
+    for (int t = 0; t < nslots; ++t) s += src[(long)t * VV + e];     // fixed order; 8 loads in flight
     D[e] = s;
     dadj[(long)ni * VV + e] = s;
   }
@@ -282,7 +284,7 @@ int agcn_adjacency_fwd(const float* tp, const float* A, const float* PA, const f
   hipLaunchKernelGGL(scores_fwd_kernel, dim3(N * ntiles, 3), dim3(256), smem, s, tp, spart, N, Ci, T, V, tt, ntiles);
   int rc = agcn_check_launch();
   if (rc) return rc;
-  hipLaunchKernelGGL(adj_finalize_kernel, dim3(N * 3), dim3(64), 0, s, (const float*)spart, A, PA, alpha, P, adj, V,
+  hipLaunchKernelGGL(adj_finalize_kernel, dim3(N * 3), dim3(256), 0, s, (const float*)spart, A, PA, alpha, P, adj, V,
                      ntiles, 1.0f / ((float)Ci * (float)T));
   return agcn_check_launch();
 }
@@ -294,7 +296,7 @@ int agcn_adjacency_bwd_softmax(const float* dadj_part, const float* P, const flo
                                void* stream) {
   if (!dadj_part || !P || !dadj || !dS || !dPA || N <= 0 || V <= 0 || V > 32 || nslots <= 0) return AGCN_ERR_ARG;
   hipStream_t s = (hipStream_t)stream;
-  hipLaunchKernelGGL(adj_bwd_kernel, dim3(N * 3), dim3(64), 0, s, dadj_part, P, alpha, dadj, dS, dalpha_part, V,
+  hipLaunchKernelGGL(adj_bwd_kernel, dim3(N * 3), dim3(256), 0, s, dadj_part, P, alpha, dadj, dS, dalpha_part, V,
                      nslots, 1.0f / ((float)Ci * (float)T));
   int rc = agcn_check_launch();
   if (rc) return rc;

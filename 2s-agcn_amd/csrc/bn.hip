@@ -143,6 +143,7 @@ __global__ void bn_bwd_finalize_kernel(const float* __restrict__ part, int N, in
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= C) return;
   double s0 = 0.0, s1 = 0.0, s2 = 0.0;
+#pragma unroll 8
   for (int n = 0; n < N; ++n) {
     const float* p = part + ((long)n * C + c) * 3;
     s0 += (double)p[0]; s1 += (double)p[1]; s2 += (double)p[2];
