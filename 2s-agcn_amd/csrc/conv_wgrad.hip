@@ -199,16 +199,29 @@ __global__ void __launch_bounds__(512) conv_wgrad_kernel(const WgradArgs a) {
       }
       const float* Bsrc = (AGG ? Bg : Bx) + (cw * 32 + lr) * (AGG ? GP : WLP) + tap0 * V;
       const float* Asrc = Da + (mw * 32 + lr) * DAP;
-      for (int s = s_begin; s < s_end; ++s) {
+      // operands are fetched one k-step ahead of the MFMAs that use them; for stride 1 the window offset of
+      // position q is q itself (no table lookup on the critical path)
+      const bool lin = AGG || a.stride == 1;
+      auto load_ops = [&](int s, float& av, float (&bv)[NTW]) __attribute__((always_inline)) {
         const int q = 2 * s + h;
-        const int qo = qoff[q];
-        const float av = Asrc[q];
-        float bv[NTW];
+        const int qo = lin ? q : qoff[q];
+        av = Asrc[q];
 #pragma unroll
         for (int t = 0; t < NTW; ++t) bv[t] = Bsrc[qo + ((TSPLIT && t >= ntaps) ? 0 : t * V)];
+      };
+      if (s_begin < s_end) {
+        float av, bv[NTW];
+        load_ops(s_begin, av, bv);
+        for (int s = s_begin; s < s_end; ++s) {
+          float an, bn[NTW];
+          load_ops(min(s + 1, s_end - 1), an, bn);
 #pragma unroll
-        for (int t = 0; t < NTW; ++t)
-          if (!TSPLIT || t < ntaps) acc[sub * NTW + t] = mfma32(av, bv[t], acc[sub * NTW + t]);
+          for (int t = 0; t < NTW; ++t)
+            if (!TSPLIT || t < ntaps) acc[sub * NTW + t] = mfma32(av, bv[t], acc[sub * NTW + t]);
+          av = an;
+#pragma unroll
+          for (int t = 0; t < NTW; ++t) bv[t] = bn[t];
+        }
       }
     }
   }
