@@ -73,6 +73,24 @@ __global__ void __launch_bounds__(256) pack_weights_kernel(const PackArgs p) {
   }
 }
 
+// One 32x32 tile of the aggregation G = X . A^: all NS operand pairs are fetched from LDS first, then the NS
+// dependent matrix-core steps run back to back (one LDS latency per tile instead of one per step).
+// Rows u >= V of the padded adjacency image are zero, so the clamped x operand needs no masking.
+template <int S0, int NS, int VMIN>   // VMIN = smallest V this chain is used with: only u >= VMIN needs the clamp
+__device__ __forceinline__ f32x16 agg_chain(const float* bxrow, const float* adjcol, int V, int h, f32x16 d) {
+  float av[NS], bv[NS];
+#pragma unroll
+  for (int s = 0; s < NS; ++s) {
+    const int u = 2 * (S0 + s) + h;
+    av[s] = (2 * (S0 + s) + 1 < VMIN) ? bxrow[u] : bxrow[min(u, V - 1)];
+    bv[s] = adjcol[u * 32];
+  }
+#pragma unroll
+  for (int s = 0; s < NS; ++s) d = mfma32(av[s], bv[s], d);
+  __builtin_amdgcn_sched_barrier(0);   // keep the next chain's operand fetches from being hoisted above this one
+  return d;
+}
+
 // WB = max number of 64-float column blocks of a staged window row (compile-time bound of the prefetch registers)
 template <int TAPS, int AGG, int WM, int WN, int TM, int TN, int CK, int WB, int EPI>
 __global__ void __launch_bounds__(WM* WN * 64, (WM * WN == 8 && TAPS == 1) ? 4 : 2) conv_gemm_kernel(const ConvGemmArgs a) {
@@ -222,15 +240,21 @@ __global__ void __launch_bounds__(WM* WN * 64, (WM * WN == 8 && TAPS == 1) ? 4 :
       for (int tl = wave; tl < 3 * nrt; tl += NW) {
         const int i = tl / nrt, rt = tl - i * nrt;
         const int row = min(rt * 32 + lr, nrows - 1);
+        const float* bxrow = Bx + row * V;
+        const float* adjcol = adjp + i * VP * 32 + lr;
         f32x16 d;
 #pragma unroll
         for (int j = 0; j < 16; ++j) d[j] = 0.f;
-        for (int s = 0; s < VS; ++s) {
-          const int u = 2 * s + h;
-          float av = Bx[row * V + min(u, V - 1)];
-          av = (u < V) ? av : 0.f;
-          const float bv = adjp[(i * VP + u) * 32 + lr];
-          d = mfma32(av, bv, d);
+        if (NW != 8 && VS == 13) {          // V = 25 (NTU)
+          d = agg_chain<0, 13, 25>(bxrow, adjcol, V, h, d);
+        } else if (NW != 8 && VS == 9) {    // V = 18 (Kinetics)
+          d = agg_chain<0, 9, 17>(bxrow, adjcol, V, h, d);
+        } else {
+          // 8-wave variant (128-register budget) and other V: plain loop (a longer unrolled chain spills there)
+          for (int s = 0; s < VS; ++s) {
+            const int u = 2 * s + h;
+            d = mfma32(bxrow[min(u, V - 1)], adjcol[u * 32], d);
+          }
         }
 #pragma unroll
         for (int j = 0; j < 16; ++j) {
@@ -563,7 +587,15 @@ size_t agcn_gcn_workspace(int C, int Cout, int T, int V) {
   size_t b = PACK_BYTES_BM(1, 1, CKA, CKA, V, T, 1, Cout, C), t;
   t = PACK_BYTES_BM(1, 2, CKA, CKA, V, T, 1, C, Cout); if (t > b) b = t;
   t = pack_bytes<1, 0, 1, 4, 2, 1, CKD, 1>(V, T, 1, 3 * C, Cout); if (t > b) b = t;
+  if (agcn_gcn_chain_supported(Cout, C, V)) { t = agcn_gcn_chain_workspace(Cout, C, T, V); if (t > b) b = t; }
+  if (agcn_gcn_chain_supported(C, Cout, V)) { t = agcn_gcn_chain_workspace(C, Cout, T, V); if (t > b) b = t; }
   return b + 256;
+}
+
+// slots per sample of the (sum, sumsq) partials agcn_gcn_aggregate_project_fwd writes for these sizes
+int agcn_gcn_stats_tiles(int C, int Cout, int T, int V) {
+  if (agcn_gemm_precision() == 3 && agcn_gcn_chain_supported(Cout, C, V)) return agcn_gcn_chain_tiles(T);
+  return agcn_conv_num_tiles(V, T);
 }
 
 // y[n][o][t,v] = bias[o] + sum_{c,k} w[o][c][k] x[n][c][(t*stride + k - pad), v]      (unit_tcn conv, 1x1 convs)
@@ -649,6 +681,9 @@ int agcn_gcn_aggregate_project_fwd(const float* x, const float* adj, const float
                                    int T, int V, void* stream) {
   if (!x || !adj || !wcat || !y || !workspace || N <= 0 || C <= 0 || Cout <= 0 || T <= 0 || V <= 0 || V > 32)
     return AGCN_ERR_ARG;
+  if (agcn_gemm_precision() == 3 && agcn_gcn_chain_supported(Cout, C, V))
+    return agcn_gcn_chain(0, x, adj, wcat, bias, y, stats_part, 0, nullptr, nullptr, nullptr, nullptr, workspace,
+                          workspace_bytes, N, C, Cout, T, V, (hipStream_t)stream);
   Problem p = {};
   ConvGemmArgs& a = p.a;
   a.in = x; a.bias = bias; a.out = y; a.adj = adj; a.stats = stats_part;
@@ -666,6 +701,9 @@ int agcn_gcn_aggregate_project_bwd_data(const float* dy, const float* adj, const
                                         int Cout, int T, int V, void* stream) {
   if (!dy || !adj || !wcat || !dx || !workspace || N <= 0 || C <= 0 || Cout <= 0 || T <= 0 || V <= 0 || V > 32)
     return AGCN_ERR_ARG;
+  if (agcn_gemm_precision() == 3 && agcn_gcn_chain_supported(C, Cout, V))
+    return agcn_gcn_chain(1, dy, adj, wcat, nullptr, dx, nullptr, accumulate, add1, mask1, add2, mask2, workspace,
+                          workspace_bytes, N, C, Cout, T, V, (hipStream_t)stream);
   Problem p = {};
   ConvGemmArgs& a = p.a;
   a.in = dy; a.out = dx; a.adj = adj; a.accumulate = accumulate;

@@ -1,0 +1,449 @@
+// unit_gcn's fused aggregate+project  y = sum_i Wd_i (x . A^_i)  (reference agcn.py:103-105) and its backward-data
+// dx = sum_i Wd_i^T (dy . A^_i^T), as a register-chained pair of matrix-core contractions:
+//
+//   wave  <->  one frame t (V <= 32 joints = one 32-column MFMA tile), all BM output rows of the block
+//   stage <->  (32-channel block cb, subset i)
+//   1. G = X[cb](32 channels x V) . A^_i (V x V)      exact-f32 MFMA chain (v_mfma_f32_32x32x2_f32), operands from LDS
+//      (x chunk staged once per cb, the sample's three padded adjacencies staged once per workgroup).
+//   2. The D registers of step 1 ARE the B operand of the projection: register j of lane (h, v) holds channel
+//      (j&3) + 8*(j>>2) + 4*h, so the 16 values of a lane are split in registers into bf16 (hi, mid, lo) pieces and
+//      fed to v_mfma_f32_32x32x16_bf16 (bf16x6: 6 products per fp32 product, fp32 accumulate = fp32-equivalent, see
+//      conv_gemm_bf16.hip) against weight images the pack kernel pre-split and pre-permuted to the same channel order.
+//   G never touches LDS or HBM, there is no aggregate barrier, and no wave idles on an uneven tile count.
+//
+// Pipeline: weight images are double-buffered in LDS; the global loads of stage s+2 (and of the next x chunk) are
+// issued into registers before the matrix-core work of stage s and committed before stage s+1: one barrier per stage.
+#include "agcn_common.h"
+
+namespace {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int CB = 32;                    // channels per stage
+
+struct ChainArgs {
+  const float* in;             // (N, K, T, V): x (forward) or dy (backward-data)
+  const unsigned short* wp;    // packed weight images [mblock][cb][i][plane][hf][tm][lane][8] (bf16)
+  const float* bias;
+  float* out;                  // (N, M, T, V)
+  const float* adj;            // (N, 3, V, V)
+  float* stats;                // [N*ntiles][2][M] or null
+  const float* add1;
+  const float* mask1;
+  const float* add2;
+  const float* mask2;
+  int N, M, K, T, V;
+  int ntiles, ncb, nmb;
+  int accumulate;
+  int adj_t;                   // 0: B[u][v] = adj[u][v] (forward); 1: B[u][v] = adj[v][u] (backward-data)
+  int XP;                      // pitch (floats) of an x chunk row in LDS (odd)
+  int off_bias;                // byte offset of the bias row in LDS
+};
+
+struct ChainPackArgs {
+  const float* w;
+  unsigned short* wp;
+  int M, K, ncb;
+  long sa_m, sa_i, sa_c;       // W_i[m][c] = w[m*sa_m + i*sa_i + c*sa_c]
+};
+
+__device__ __forceinline__ unsigned pack_bf16(float a, float b) {
+  f32x2 v = {a, b};
+  bf16x2 p = __builtin_convertvector(v, bf16x2);      // v_cvt_pk_bf16_f32 (round to nearest even)
+  return __builtin_bit_cast(unsigned, p);
+}
+__device__ __forceinline__ float lo_as_f32(unsigned p) { return __builtin_bit_cast(float, p << 16); }
+__device__ __forceinline__ float hi_as_f32(unsigned p) { return __builtin_bit_cast(float, p & 0xffff0000u); }
+__device__ __forceinline__ void split_pair(float a, float b, unsigned& ph, unsigned& pm, unsigned& pl) {
+  ph = pack_bf16(a, b);
+  const float ra = a - lo_as_f32(ph), rb = b - hi_as_f32(ph);
+  pm = pack_bf16(ra, rb);
+  pl = pack_bf16(ra - lo_as_f32(pm), rb - hi_as_f32(pm));
+}
+
+// channel (within the 32-block) that slot e of lane-half h carries in projection half hf: D register j = 8*hf + e
+__host__ __device__ __forceinline__ int chain_channel(int hf, int h, int e) {
+  const int j = 8 * hf + e;
+  return (j & 3) + 8 * (j >> 2) + 4 * h;
+}
+
+// one block per (mblock, cb, i) image: [plane][hf][tm][lane][8]
+template <int TM>
+__global__ void __launch_bounds__(256) chain_pack_kernel(const ChainPackArgs p) {
+  constexpr int BM = TM * 32;
+  constexpr int PER_PLANE = 2 * TM * 64 * 8;          // bf16 elements
+  const int i = blockIdx.x % 3;
+  const int cb = (blockIdx.x / 3) % p.ncb;
+  const int mb = blockIdx.x / (3 * p.ncb);
+  unsigned short* dst = p.wp + (long)blockIdx.x * 3 * PER_PLANE;
+  for (int e = threadIdx.x; e < PER_PLANE / 2; e += 256) {     // one bf16 pair per iteration
+    const int e2 = e & 3;                 // slot pair (2*e2, 2*e2+1)
+    const int lane = (e >> 2) & 63;
+    const int r = e >> 8;
+    const int tm = r % TM, hf = r / TM;
+    const int h = lane >> 5, lr = lane & 31;
+    const int m = mb * BM + tm * 32 + lr;
+    float v[2];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      const int c = cb * CB + chain_channel(hf, h, 2 * e2 + q);
+      v[q] = (m < p.M && c < p.K) ? p.w[(long)m * p.sa_m + (long)i * p.sa_i + (long)c * p.sa_c] : 0.f;
+    }
+    unsigned ph, pm, pl;
+    split_pair(v[0], v[1], ph, pm, pl);
+    const int o = ((hf * TM + tm) * 64 + lane) * 8 + 2 * e2;
+    *reinterpret_cast<unsigned*>(dst + 0 * PER_PLANE + o) = ph;
+    *reinterpret_cast<unsigned*>(dst + 1 * PER_PLANE + o) = pm;
+    *reinterpret_cast<unsigned*>(dst + 2 * PER_PLANE + o) = pl;
+  }
+}
+
+// VS >= (V+1)/2 aggregation steps (13: NTU V=25, 9: Kinetics V=18, 16: any V <= 32; surplus steps multiply zero rows)
+// NW waves per workgroup = frames per workgroup tile (one frame per wave)
+template <int TM, int VS, int NW>
+__global__ void __launch_bounds__(NW * 64, 2) gcn_chain_kernel(const ChainArgs a) {
+  constexpr int NT = NW * 64, FT = NW;
+  constexpr int BM = TM * 32;
+  constexpr int A_IMG = 3 * 2 * TM * 1024;             // bytes of one stage's weight image
+  constexpr int A16 = A_IMG / 16;
+  constexpr int EA = (A16 + NT - 1) / NT;
+  constexpr int XB = FT / 2;                           // 64-float column blocks of a staged x row (V <= 32)
+  constexpr int XR = CB / NW;                          // x rows per wave
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  float* adjp = reinterpret_cast<float*>(smem);                       // [3][32][32]
+  float* xb = adjp + 3 * 32 * 32;                                     // [CB][XP]
+  const int xb_bytes = ((CB * a.XP * 4 + 15) & ~15);
+  unsigned char* abuf = smem + 3 * 32 * 32 * 4 + xb_bytes;            // [2][A_IMG]
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int lr = lane & 31, h = lane >> 5;
+  const int bid = xcd_remap(blockIdx.x, gridDim.x);
+  const int mbk = bid % a.nmb;
+  const int nt_id = bid / a.nmb;
+  const int n = nt_id / a.ntiles, tile_id = nt_id - n * a.ntiles;
+  const int m0 = mbk * BM;
+  const int V = a.V, T = a.T, XP = a.XP;
+  const int t0 = tile_id * FT;
+  const int t = t0 + wave;
+  const bool fvalid = t < T;                           // wave-uniform
+  const int xlen = min(FT, T - t0) * V;                // valid floats of a staged x row
+  const long P = (long)T * V;
+  const int S = 3 * a.ncb;
+
+  // bias of this row block, beyond everything the epilogue tile overwrites
+  float* bias_s = reinterpret_cast<float*>(smem + a.off_bias);
+  for (int e = tid; e < BM; e += NT) bias_s[e] = (a.bias && m0 + e < a.M) ? a.bias[m0 + e] : 0.f;
+
+  // ---- the sample's adjacencies, zero padded to 32x32 (rows u >= V are zero: clamped x operands need no mask) ----
+  {
+    const float* adjn = a.adj + (long)n * 3 * V * V;
+    for (int e = tid; e < 3 * 32 * 32; e += NT) {
+      const int i = e >> 10, u = (e >> 5) & 31, col = e & 31;
+      const bool ok = u < V && col < V;
+      const int gi = ok ? (a.adj_t ? ((i * V + col) * V + u) : ((i * V + u) * V + col)) : 0;
+      const float tv = adjn[gi];
+      adjp[e] = ok ? tv : 0.f;
+    }
+  }
+
+  f32x16 acc[TM];
+#pragma unroll
+  for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+    for (int j = 0; j < 16; ++j) acc[tm][j] = 0.f;
+
+  // ---- prefetch registers (raw loads; predicates are re-evaluated at commit) ----
+  u32x4 ra[EA];
+  float rx[XR][XB];
+  const u32x4* wp4 = reinterpret_cast<const u32x4*>(a.wp) + (long)mbk * S * A16;
+  auto issue_A = [&](int s) __attribute__((always_inline)) {
+    const u32x4* src = wp4 + (long)s * A16;
+#pragma unroll
+    for (int u = 0; u < EA; ++u) ra[u] = src[min(tid + u * NT, A16 - 1)];
+  };
+  auto commit_A = [&](int s) __attribute__((always_inline)) {
+    u32x4* dst = reinterpret_cast<u32x4*>(abuf + (s & 1) * A_IMG);
+#pragma unroll
+    for (int u = 0; u < EA; ++u)
+      if (tid + u * NT < A16) dst[tid + u * NT] = ra[u];
+  };
+  auto issue_X = [&](int cb) __attribute__((always_inline)) {
+#pragma unroll
+    for (int j = 0; j < XR; ++j) {
+      const int c = cb * CB + wave * XR + j;
+      const float* rowp = a.in + ((long)n * a.K + min(c, a.K - 1)) * P + (long)t0 * V;
+#pragma unroll
+      for (int u = 0; u < XB; ++u) {
+        const int q = lane + 64 * u;
+        rx[j][u] = rowp[(q < xlen) ? q : 0];
+      }
+    }
+  };
+  auto commit_X = [&](int cb) __attribute__((always_inline)) {
+#pragma unroll
+    for (int j = 0; j < XR; ++j) {
+      const int cl = wave * XR + j;
+      const bool rok = (cb * CB + cl) < a.K;
+#pragma unroll
+      for (int u = 0; u < XB; ++u) {
+        const int q = lane + 64 * u;
+        if (q < FT * V) xb[cl * XP + q] = (rok && q < xlen) ? rx[j][u] : 0.f;
+      }
+    }
+  };
+
+  // prologue: stage 0 (and 1) in place before the loop
+  issue_A(0);
+  issue_X(0);
+  commit_A(0);
+  commit_X(0);
+  if (S > 1) issue_A(1);
+  __syncthreads();
+
+  float xo[VS];
+  for (int s = 0; s < S; ++s) {
+    const int cb = s / 3, i = s - cb * 3;
+    if (s + 1 < S) commit_A(s + 1);                    // loads were issued one stage ago
+    if (i == 2 && cb + 1 < a.ncb) commit_X(cb + 1);    // xb is free: every wave took its operands at i == 0
+    if (s + 2 < S) issue_A(s + 2);
+    if (i == 0 && cb + 1 < a.ncb) issue_X(cb + 1);
+    if (fvalid) {
+      // ---- 1. G = X[cb] . A^_i for this wave's frame ----
+      const float* xr = xb + lr * XP + wave * V;
+      const float* ar = adjp + i * 1024 + lr;
+      f32x16 d;
+#pragma unroll
+      for (int j = 0; j < 16; ++j) d[j] = 0.f;
+      if (i == 0) {
+#pragma unroll
+        for (int k = 0; k < VS; ++k) xo[k] = xr[min(2 * k + h, V - 1)];
+      }
+      float bo[VS];
+#pragma unroll
+      for (int k = 0; k < VS; ++k) bo[k] = ar[(2 * k + h) * 32];
+#pragma unroll
+      for (int k = 0; k < VS; ++k) d = mfma32(xo[k], bo[k], d);
+      // ---- 2. split G in registers and project: acc[tm] += W_i[:, cb] . G ----
+      const unsigned char* ab = abuf + (s & 1) * A_IMG + lane * 16;
+#pragma unroll
+      for (int hf = 0; hf < 2; ++hf) {
+        u32x4 gh, gm, gl;
+#pragma unroll
+        for (int e2 = 0; e2 < 4; ++e2) {
+          unsigned p0, p1, p2;
+          split_pair(d[8 * hf + 2 * e2], d[8 * hf + 2 * e2 + 1], p0, p1, p2);
+          gh[e2] = p0; gm[e2] = p1; gl[e2] = p2;
+        }
+        const bf16x8 b0 = __builtin_bit_cast(bf16x8, gh), b1 = __builtin_bit_cast(bf16x8, gm),
+                     b2 = __builtin_bit_cast(bf16x8, gl);
+#pragma unroll
+        for (int tm = 0; tm < TM; ++tm) {
+          const bf16x8 a0 = *reinterpret_cast<const bf16x8*>(ab + ((0 * 2 + hf) * TM + tm) * 1024);
+          const bf16x8 a1 = *reinterpret_cast<const bf16x8*>(ab + ((1 * 2 + hf) * TM + tm) * 1024);
+          const bf16x8 a2 = *reinterpret_cast<const bf16x8*>(ab + ((2 * 2 + hf) * TM + tm) * 1024);
+          // smallest products first
+          acc[tm] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, b0, acc[tm], 0, 0, 0);
+          acc[tm] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b2, acc[tm], 0, 0, 0);
+          acc[tm] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b1, acc[tm], 0, 0, 0);
+          acc[tm] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b0, acc[tm], 0, 0, 0);
+          acc[tm] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b1, acc[tm], 0, 0, 0);
+          acc[tm] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b0, acc[tm], 0, 0, 0);
+        }
+      }
+    }
+    __syncthreads();
+  }
+
+  // ---- epilogue: the block's (BM x FT*V) tile goes through LDS so that every row is stored (and its residual /
+  // accumulate operands loaded) as one contiguous run; a row belongs to one wave, which also reduces its
+  // (sum, sumsq) partials ----
+  // Row groups are software-pipelined: the residual / accumulate operands of group k+1 are loaded RAW into registers
+  // (nothing consumes them yet) while group k is combined and stored, so their latency overlaps the stores.
+  constexpr int RG = 4, NG = BM / (NW * RG);
+  const bool has_extra = a.accumulate || a.add1 || a.add2;   // kernel-uniform
+  float ex[2][5][RG][XB];                              // [buffer][out, add1, mask1, add2, mask2]
+  auto row_base = [&](int k, int g) __attribute__((always_inline)) {
+    const int m = min(m0 + (k * NW + wave) * RG + g, a.M - 1);
+    return (((long)n * a.M + m) * T + t0) * V;
+  };
+  auto load_extras = [&](int k, float (&e)[5][RG][XB]) __attribute__((always_inline)) {
+#pragma unroll
+    for (int g = 0; g < RG; ++g) {
+      const long base = row_base(k, g);
+#pragma unroll
+      for (int u = 0; u < XB; ++u) {
+        const int q = lane + 64 * u;
+        const long idx = base + ((q < xlen) ? q : 0);
+        if (a.accumulate) e[0][g][u] = a.out[idx];
+        if (a.add1) e[1][g][u] = a.add1[idx];
+        if (a.mask1) e[2][g][u] = a.mask1[idx];
+        if (a.add2) e[3][g][u] = a.add2[idx];
+        if (a.mask2) e[4][g][u] = a.mask2[idx];
+      }
+    }
+  };
+  if (has_extra) load_extras(0, ex[0]);                // in flight across the tile transposition below
+  float* tile = reinterpret_cast<float*>(smem);        // [BM][TP]; the loop's final barrier freed all of LDS
+  const int TP = (FT * V) | 1;                         // odd pitch: column walks over consecutive rows are conflict-free
+  if (lr < V) {
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+      for (int j = 0; j < 16; ++j) tile[(tm * 32 + mfma_row(j, h)) * TP + wave * V + lr] = acc[tm][j];
+  }
+  __syncthreads();
+  if (a.stats) {
+    // per-channel (sum, sumsq) of y = tile + bias over the tile's valid positions: thread <-> (row, column slice)
+    constexpr int NP = NT / BM;
+    float* red = tile + BM * TP;                       // [NP][2][BM]
+    const int r = tid % BM, part = tid / BM;
+    const float bval = bias_s[r];
+    float bsum = 0.f, bsq = 0.f;
+#pragma unroll 8
+    for (int q = part; q < xlen; q += NP) {
+      const float y = tile[r * TP + q] + bval;
+      bsum += y;
+      bsq += y * y;
+    }
+    red[(part * 2 + 0) * BM + r] = bsum;
+    red[(part * 2 + 1) * BM + r] = bsq;
+    __syncthreads();
+    const long slot = (long)n * a.ntiles + tile_id;
+    for (int e = tid; e < 2 * BM; e += NT) {
+      const int k = e / BM, ml = e - k * BM;
+      float sum = 0.f;
+#pragma unroll
+      for (int p2 = 0; p2 < NP; ++p2) sum += red[(p2 * 2 + k) * BM + ml];
+      if (m0 + ml < a.M) a.stats[(slot * 2 + k) * a.M + m0 + ml] = sum;
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < NG; ++k) {
+    const int r0 = (k * NW + wave) * RG;
+    if (m0 + r0 >= a.M) break;                         // wave-uniform
+    if (has_extra && k + 1 < NG) load_extras(k + 1, ex[(k + 1) & 1]);
+#pragma unroll
+    for (int g = 0; g < RG; ++g) {
+      const int m = m0 + r0 + g;
+      if (m >= a.M) break;                             // wave-uniform
+      const long base = row_base(k, g);
+      const float bval = bias_s[r0 + g];
+#pragma unroll
+      for (int u = 0; u < XB; ++u) {
+        const int q = lane + 64 * u;
+        float v = tile[(r0 + g) * TP + min(q, TP - 1)] + bval;
+        if (a.accumulate) v += ex[k & 1][0][g][u];
+        if (a.add1) v += (!a.mask1 || ex[k & 1][2][g][u] > 0.f) ? ex[k & 1][1][g][u] : 0.f;
+        if (a.add2) v += (!a.mask2 || ex[k & 1][4][g][u] > 0.f) ? ex[k & 1][3][g][u] : 0.f;
+        if (q < xlen) a.out[base + q] = v;
+      }
+    }
+  }
+}
+
+struct ChainGeom {
+  int ntiles, ncb, nmb, XP, off_bias;
+  size_t smem_bytes, pack_bytes;
+};
+
+template <int TM, int NW>
+ChainGeom chain_geometry(int V, int T, int M, int K) {
+  constexpr int BM = TM * 32, FT = NW;
+  ChainGeom g;
+  g.ntiles = (T + FT - 1) / FT;
+  g.ncb = (K + CB - 1) / CB;
+  g.nmb = (M + BM - 1) / BM;
+  g.XP = (FT * V) | 1;
+  const size_t a_img = (size_t)3 * 2 * TM * 1024;
+  const size_t xb_bytes = ((size_t)CB * g.XP * 4 + 15) & ~(size_t)15;
+  g.smem_bytes = (size_t)3 * 32 * 32 * 4 + xb_bytes + 2 * a_img;
+  const size_t epi_bytes = (size_t)BM * ((FT * V) | 1) * 4 + (size_t)NW * 64 * 2 * 4;
+  if (epi_bytes > g.smem_bytes) g.smem_bytes = epi_bytes;
+  g.smem_bytes = (g.smem_bytes + 15) & ~(size_t)15;
+  g.off_bias = (int)g.smem_bytes;
+  g.smem_bytes += (size_t)BM * 4;
+  g.pack_bytes = (size_t)g.nmb * g.ncb * 3 * a_img;
+  return g;
+}
+
+template <int TM, int VS, int NW>
+int chain_launch(ChainArgs a, const float* w, long sa_m, long sa_i, long sa_c, void* ws, size_t ws_bytes,
+                 hipStream_t stream) {
+  const ChainGeom g = chain_geometry<TM, NW>(a.V, a.T, a.M, a.K);
+  if (g.smem_bytes > 160 * 1024) return AGCN_ERR_UNSUPPORTED;
+  if (g.pack_bytes > ws_bytes) return AGCN_ERR_WORKSPACE;
+  a.ntiles = g.ntiles; a.ncb = g.ncb; a.nmb = g.nmb; a.XP = g.XP; a.off_bias = g.off_bias;
+  a.wp = (const unsigned short*)ws;
+  ChainPackArgs pk;
+  pk.w = w; pk.wp = (unsigned short*)ws; pk.M = a.M; pk.K = a.K; pk.ncb = g.ncb;
+  pk.sa_m = sa_m; pk.sa_i = sa_i; pk.sa_c = sa_c;
+  hipLaunchKernelGGL((chain_pack_kernel<TM>), dim3(g.nmb * g.ncb * 3), dim3(256), 0, stream, pk);
+  int rc = agcn_check_launch();
+  if (rc) return rc;
+  auto kern = gcn_chain_kernel<TM, VS, NW>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e != hipSuccess) return (int)e;
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(kern, dim3((unsigned)(a.N * g.ntiles * g.nmb)), dim3(NW * 64), g.smem_bytes, stream, a);
+  return agcn_check_launch();
+}
+
+template <int TM, int NW>
+int chain_dispatch_vs(const ChainArgs& a, const float* w, long sa_m, long sa_i, long sa_c, void* ws, size_t ws_bytes,
+                      hipStream_t stream) {
+  const int vs = (a.V + 1) / 2;
+  if (vs == 13) return chain_launch<TM, 13, NW>(a, w, sa_m, sa_i, sa_c, ws, ws_bytes, stream);
+  if (vs == 9) return chain_launch<TM, 9, NW>(a, w, sa_m, sa_i, sa_c, ws, ws_bytes, stream);
+  return chain_launch<TM, 16, NW>(a, w, sa_m, sa_i, sa_c, ws, ws_bytes, stream);
+}
+
+}  // namespace
+
+// rows per block: 128 when M is a multiple of 128, else 64
+static inline int chain_tm(int M) { return (M % 128 == 0) ? 4 : 2; }
+
+// waves (= frames) per workgroup: 4 (two workgroups per CU overlap each other's prologue/epilogue) or 8
+static inline int chain_waves() {
+  static int nw = 0;
+  if (!nw) {
+    const char* e = getenv("AGCN_CHAIN_WAVES");
+    nw = (e && atoi(e) == 8) ? 8 : 4;
+  }
+  return nw;
+}
+
+bool agcn_gcn_chain_supported(int M, int K, int V) { return M >= 64 && K >= CB && V <= 32; }
+
+int agcn_gcn_chain_tiles(int T) { return (T + chain_waves() - 1) / chain_waves(); }
+
+size_t agcn_gcn_chain_workspace(int M, int K, int T, int V) {   // pack size does not depend on the frame tile
+  return chain_tm(M) == 4 ? chain_geometry<4, 8>(V, T, M, K).pack_bytes : chain_geometry<2, 8>(V, T, M, K).pack_bytes;
+}
+
+// mode 0: forward (in = x, K = C, M = Cout); mode 1: backward-data (in = dy, K = Cout, M = C)
+int agcn_gcn_chain(int mode, const float* in, const float* adj, const float* wcat, const float* bias, float* out,
+                   float* stats_part, int accumulate, const float* add1, const float* mask1, const float* add2,
+                   const float* mask2, void* ws, size_t ws_bytes, int N, int C, int Cout, int T, int V,
+                   hipStream_t stream) {
+  ChainArgs a = {};
+  a.in = in; a.adj = adj; a.bias = bias; a.out = out; a.stats = stats_part;
+  a.accumulate = accumulate; a.add1 = add1; a.mask1 = mask1; a.add2 = add2; a.mask2 = mask2;
+  a.N = N; a.T = T; a.V = V;
+  long sa_m, sa_i, sa_c;
+  if (mode == 0) { a.M = Cout; a.K = C; a.adj_t = 0; sa_m = 3L * C; sa_i = C; sa_c = 1; }
+  else           { a.M = C; a.K = Cout; a.adj_t = 1; sa_m = 1; sa_i = C; sa_c = 3L * C; }
+  if (chain_waves() == 8) {
+    if (chain_tm(a.M) == 4) return chain_dispatch_vs<4, 8>(a, wcat, sa_m, sa_i, sa_c, ws, ws_bytes, stream);
+    return chain_dispatch_vs<2, 8>(a, wcat, sa_m, sa_i, sa_c, ws, ws_bytes, stream);
+  }
+  if (chain_tm(a.M) == 4) return chain_dispatch_vs<4, 4>(a, wcat, sa_m, sa_i, sa_c, ws, ws_bytes, stream);
+  return chain_dispatch_vs<2, 4>(a, wcat, sa_m, sa_i, sa_c, ws, ws_bytes, stream);
+}

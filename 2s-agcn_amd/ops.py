@@ -112,7 +112,7 @@ def aggregate_project_fwd(x, adj, wcat, bias, want_stats=False):
     y = _empty((N, Cout, T, V), x)
     stats = None
     if want_stats:
-        nt = _L().agcn_conv_num_tiles(V, T)
+        nt = _L().agcn_gcn_stats_tiles(C, Cout, T, V)
         stats = _empty((N * nt, 2, Cout), x)
     ws, nb = _gcn_ws(C, Cout, T, V, x)
     _lib.check(_L().agcn_gcn_aggregate_project_fwd(_lib.ptr(x), _lib.ptr(adj), _lib.ptr(wcat), _lib.ptr(bias),

@@ -108,6 +108,52 @@ def dominant_kernel_roofline(device, reps=10):
             "algorithmic_bytes_per_launch": 4.0 * 2 * N * C * T * V}
 
 
+GCN_LAYER_SHAPES = [  # (name, C, Cout, T) at N'=128, V=25: the distinct unit_gcn shapes of configs[1]
+    ('l1', 3, 64, 300), ('l2-4', 64, 64, 300), ('l5', 64, 128, 300), ('l6-7', 128, 128, 150),
+    ('l8', 128, 256, 150), ('l9-10', 256, 256, 75)]
+
+
+def unit_gcn_forward_roofline(device, reps=5, Np=128, V=25):
+    """unit_gcn forward alone (reference agcn.py:92-109, train-mode BN), one entry per layer shape, timed with HIP
+    events on the launch stream.  Algorithmic work per SURVEY 8(d): FLOPs = theta/phi + S + aggregate + project
+    (+ down); bytes = read x once + write y once.  Roofline time = max(bytes / 8 TB/s, FLOPs / 157.3 TFLOP/s) - the
+    whole unit computes in exact-f32 MFMA, so the f32 matrix rate is the compute ceiling.  frac = roofline / measured."""
+    import agcn_amd  # noqa: F401
+    from agcn_amd import ops
+    from agcn_amd.model.agcn import unit_gcn
+    from agcn_amd.graph.ntu_rgb_d import Graph
+    A = Graph().A
+    rows = []
+    for name, C, Cout, T in GCN_LAYER_SHAPES:
+        torch.manual_seed(0)
+        m = unit_gcn(C, Cout, A).to(device).train()
+        with torch.no_grad():
+            m.bn.weight.fill_(1.0)
+        x = torch.randn(Np, C, T, V, device=device)
+        with torch.no_grad():
+            for _ in range(2):
+                m(x)
+            torch.cuda.synchronize()
+            s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            s.record()
+            for _ in range(reps):
+                m(x)
+            e.record()
+            torch.cuda.synchronize()
+        ms = s.elapsed_time(e) / reps
+        Ci = Cout // 4
+        flops = Np * (6 * 2 * C * Ci * T * V + 3 * 2 * V * V * Ci * T + 3 * 2 * C * T * V * V +
+                      3 * 2 * C * Cout * T * V + (2 * C * Cout * T * V if C != Cout else 0))
+        nbytes = 4.0 * Np * (C + Cout) * T * V
+        t_hbm, t_mfma = nbytes / 8e12 * 1e3, flops / (PEAK_FP32_MFMA_TFLOPS * 1e12) * 1e3
+        roof = max(t_hbm, t_mfma)
+        rows.append({"layer": name, "shape": [Np, C, Cout, T, V], "ms": round(ms, 4),
+                     "bound": "hbm" if t_hbm > t_mfma else "mfma", "roofline_ms": round(roof, 4),
+                     "frac": round(roof / ms, 4), "GBps": round(nbytes / ms / 1e6, 1),
+                     "TFLOPs": round(flops / ms / 1e9, 2)})
+    return rows
+
+
 def host_cores():
     """CPU share of this process: the affinity mask, capped at the 16 cores a one-GPU box grants."""
     try:
@@ -235,6 +281,7 @@ def main():
         }
         if world == 1 and not args.no_roofline and args.workload == 'ntu_agcn':
             out["roofline"] = dominant_kernel_roofline(device)
+            out["unit_gcn_fwd"] = unit_gcn_forward_roofline(device)
             print("[bench] roofline done", file=sys.stderr, flush=True)
         if world == 1 and not args.no_cpu_baseline and args.workload == 'ntu_agcn':
             out["cpu_baseline"] = cpu_baseline()

@@ -1,0 +1,65 @@
+"""Time the unit_gcn contraction kernels per layer shape with HIP events (N'=128, V=25).
+    python tools/bench_gcn.py [fwd,bwd,dadj,wgrad] [layer names...]     e.g.  python tools/bench_gcn.py fwd,bwd l9"""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+import agcn_amd
+from agcn_amd import ops, lib
+dev = torch.device('cuda:0')
+SHAPES = {'l1': (3, 64, 300), 'l2': (64, 64, 300), 'l5': (64, 128, 300), 'l6': (128, 128, 150), 'l8': (128, 256, 150),
+          'l9': (256, 256, 75)}
+which = sys.argv[1].split(',') if len(sys.argv) > 1 else ['fwd', 'bwd', 'dadj', 'wgrad']
+layers = sys.argv[2:] or list(SHAPES)
+reps = int(os.environ.get('REPS', '5'))
+N, V = 128, 25
+g = torch.Generator().manual_seed(0)
+
+
+def timed(fn):
+    for _ in range(2):
+        fn()
+    torch.cuda.synchronize()
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    s.record()
+    for _ in range(reps):
+        fn()
+    e.record()
+    torch.cuda.synchronize()
+    return s.elapsed_time(e) / reps * 1e3
+
+
+for name in layers:
+    C, Cout, T = SHAPES[name]
+    x = torch.randn(N, C, T, V, generator=g).to(dev)
+    dy = torch.randn(N, Cout, T, V, generator=g).to(dev)
+    adj = (0.2 * torch.randn(N, 3, V, V, generator=g)).to(dev)
+    w = (torch.randn(Cout, 3 * C, generator=g) / (3 * C) ** 0.5).to(dev)
+    b = torch.zeros(Cout, device=dev)
+    proj = 3 * 2 * C * Cout * T * V * N
+    agg = 3 * 2 * C * T * V * V * N
+    out = [f'{name:4s} C{C:3d}->{Cout:3d} T{T:3d}']
+    if 'fwd' in which:
+        us = timed(lambda: ops.aggregate_project_fwd(x, adj, w, b, want_stats=True))
+        out.append(f'fwd {us:7.0f} us {(proj + agg) / us / 1e6:6.1f} TF')
+    if 'fwdn' in which:
+        us = timed(lambda: ops.aggregate_project_fwd(x, adj, w, b, want_stats=False))
+        out.append(f'fwdn {us:7.0f} us {(proj + agg) / us / 1e6:6.1f} TF')
+    if 'bwd' in which:
+        aggb = 3 * 2 * Cout * T * V * V * N
+        us = timed(lambda: ops.aggregate_project_bwd_data(dy, adj, w, tuple(x.shape)))
+        out.append(f'bwd {us:7.0f} us {(proj + aggb) / us / 1e6:6.1f} TF')
+    if 'bwdx' in which:   # as in training: identity-residual gradient folded in (add1 masked by the forward output)
+        aggb = 3 * 2 * Cout * T * V * V * N
+        us = timed(lambda: ops.aggregate_project_bwd_data(dy, adj, w, tuple(x.shape), add1=x, mask1=x))
+        out.append(f'bwdx {us:7.0f} us {(proj + aggb) / us / 1e6:6.1f} TF')
+    if 'dadj' in which:
+        L = ops._L(); ns = L.agcn_dadj_num_slots(C, V, T)
+        dpart = torch.empty((N, 3, ns, V, V), device=dev)
+        ws, nb = ops._gcn_ws(C, Cout, T, V, x)
+        us = timed(lambda: lib.check(L.agcn_gcn_dadj(lib.ptr(dy), lib.ptr(w), lib.ptr(x), lib.ptr(dpart), ws.data_ptr(),
+                                                     nb, N, C, Cout, T, V, lib.stream()), 'dadj'))
+        out.append(f'dadj {us:7.0f} us {(proj + agg) / us / 1e6:6.1f} TF')
+    if 'wgrad' in which:
+        us = timed(lambda: ops.project_bwd_weight(dy, x, adj, Cout))
+        out.append(f'wgrad {us:7.0f} us {(proj + agg) / us / 1e6:6.1f} TF')
+    print('  '.join(out), flush=True)
