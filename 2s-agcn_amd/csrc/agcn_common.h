@@ -49,6 +49,13 @@ int agcn_bf16_conv9_bwd_data(const float* dy, const float* w, float* dx, int acc
                              const float* mask1, const float* add2, const float* mask2, void* ws, size_t ws_bytes,
                              int N, int Cin, int Cout, int T, int V, int stride, int npl, hipStream_t s);
 
+size_t agcn_bf16_conv1_workspace(int Cin, int Cout, int T, int V, int stride);
+int agcn_bf16_conv1_fwd(const float* x, const float* w, const float* bias, float* y, float* stats_part, void* ws,
+                        size_t ws_bytes, int N, int Cin, int Cout, int T, int V, int stride, int npl, hipStream_t s);
+int agcn_bf16_conv1_bwd_data(const float* dy, const float* w, float* dx, int accumulate, const float* add1,
+                             const float* mask1, const float* add2, const float* mask2, void* ws, size_t ws_bytes,
+                             int N, int Cin, int Cout, int T, int V, int npl, hipStream_t s);
+
 // register-chained aggregate+project (gcn_chain.hip); mode 0 = forward, 1 = backward-data
 bool agcn_gcn_chain_supported(int M, int K, int V);
 int agcn_gcn_chain_tiles(int T);
@@ -57,6 +64,12 @@ int agcn_gcn_chain(int mode, const float* in, const float* adj, const float* wca
                    float* stats_part, int accumulate, const float* add1, const float* mask1, const float* add2,
                    const float* mask2, void* ws, size_t ws_bytes, int N, int C, int Cout, int T, int V,
                    hipStream_t stream);
+
+bool agcn_gcn_dadj_chain_supported(int C, int V);
+int agcn_gcn_dadj_chain_slots(int C, int T);
+size_t agcn_gcn_dadj_chain_workspace(int C, int Cout);
+int agcn_gcn_dadj_chain(const float* dy, const float* wcat, const float* x, float* dadj_part, void* ws, size_t ws_bytes,
+                        int N, int C, int Cout, int T, int V, hipStream_t stream);
 
 // GEMM arithmetic of the 9x1 temporal convolutions (forward / backward-data): 3 = bf16x6 (default: fp32-equivalent
 // accuracy, measured), 0 = f32 MFMA, 2 = bf16x3 (~5e-6 per GEMM; does NOT hold the 1e-4 parity bar end to end).

@@ -96,7 +96,7 @@ __global__ void __launch_bounds__(256) pack_weights_bf16_kernel(const BfPackArgs
 
 // NPL = 3: bf16x6 (fp32-equivalent) ; NPL = 2: bf16x3.  WQ = 64-row blocks per staging quarter (2: windows <= 512 rows)
 template <int TAPS, int NPL, int WQ, int TM>
-__global__ void __launch_bounds__(NT, 2) conv_gemm_bf16_kernel(const BfArgs a) {
+__global__ void __launch_bounds__(NT, (TAPS == 1 && TM == 2) ? 4 : 2) conv_gemm_bf16_kernel(const BfArgs a) {
   constexpr int BM = TM * 32;
   constexpr int A_PLANE = TAPS * 2 * BM * 16;          // bytes per plane of the A image
   constexpr int A4 = NPL * A_PLANE / 16;               // 16-byte units of the A image that are used
@@ -422,4 +422,45 @@ int agcn_bf16_conv9_bwd_data(const float* dy, const float* w, float* dx, int acc
   p.tap_add = 1;
   if (a.T_out > 0) rc = launch_npl<4, 2>(p, npl, s);
   return rc;
+}
+
+// 1x1 convolutions (conv_a/conv_b/down/residual; reference agcn.py:66-75,122-125) on the same kernel, TAPS = 1
+int agcn_bf16_conv1_fwd(const float* x, const float* w, const float* bias, float* y, float* stats_part, void* ws,
+                        size_t ws_bytes, int N, int Cin, int Cout, int T, int V, int stride, int npl,
+                        hipStream_t s) {
+  BfProblem p = {};
+  BfArgs& a = p.a;
+  a.in = x; a.bias = bias; a.out = y; a.stats = stats_part;
+  a.N = N; a.M = Cout; a.Kinner = Cin; a.in_rows = Cin; a.V = V;
+  a.T_src = T; a.T_out = (T - 1) / stride + 1; a.T_full = a.T_out;
+  a.src_stride = stride; a.f_off = 0; a.out_fs = 1; a.out_fo = 0;
+  p.w = w; p.sa_m = Cin; p.sa_c = 1; p.tap_flip_from = -1;
+  p.ws = ws; p.ws_bytes = ws_bytes;
+  if (stride == 1) return launch_npl<1, 2>(p, npl, s);
+  return launch_npl<1, 3>(p, npl, s);
+}
+
+// stride 1 only (the stride-2 1x1 backward is a scatter to even frames: conv_gemm.hip keeps it)
+int agcn_bf16_conv1_bwd_data(const float* dy, const float* w, float* dx, int accumulate, const float* add1,
+                             const float* mask1, const float* add2, const float* mask2, void* ws, size_t ws_bytes,
+                             int N, int Cin, int Cout, int T, int V, int npl, hipStream_t s) {
+  BfProblem p = {};
+  BfArgs& a = p.a;
+  a.in = dy; a.out = dx; a.accumulate = accumulate;
+  a.add1 = add1; a.mask1 = mask1; a.add2 = add2; a.mask2 = mask2;
+  a.N = N; a.M = Cin; a.Kinner = Cout; a.in_rows = Cout; a.V = V;
+  a.T_src = T; a.T_full = T; a.src_stride = 1;
+  a.T_out = T; a.out_fs = 1; a.out_fo = 0; a.f_off = 0;
+  p.w = w; p.sa_m = 1; p.sa_c = Cin; p.tap_mul = 1; p.tap_add = 0; p.tap_flip_from = 0;
+  p.ws = ws; p.ws_bytes = ws_bytes;
+  return launch_npl<1, 2>(p, npl, s);
+}
+
+size_t agcn_bf16_conv1_workspace(int Cin, int Cout, int T, int V, int stride) {
+  const int To = (T - 1) / stride + 1;
+  size_t b = bf_geometry<1, 64>(V, To, stride, Cout, Cin).pack_bytes, t;
+  t = bf_geometry<1, 64>(V, T, 1, Cin, Cout).pack_bytes; if (t > b) b = t;
+  t = bf_geometry<1, 128>(V, To, stride, Cout, Cin).pack_bytes; if (t > b) b = t;
+  t = bf_geometry<1, 128>(V, T, 1, Cin, Cout).pack_bytes; if (t > b) b = t;
+  return b + 256;
 }

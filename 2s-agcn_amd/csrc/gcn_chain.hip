@@ -405,6 +405,247 @@ int chain_dispatch_vs(const ChainArgs& a, const float* w, long sa_m, long sa_i, 
   return chain_launch<TM, 16, NW>(a, w, sa_m, sa_i, sa_c, ws, ws_bytes, stream);
 }
 
+
+// ------------------------------------------------------------------------------------------------------------------
+// Adjacency gradient  dA^_i[u][v] = sum_{c,t} x[c][t,u] * H_i[c][t,v],   H_i = Wd_i^T dy   (reference agcn.py:102-105
+// differentiated).  Same wave <-> frame mapping: the projection H (split-bf16 MFMA, K = Cout) leaves
+// a 32-channel x V tile per accumulator whose D registers feed the exact-f32 reduction MFMA against x directly
+// (k-pair of register j = channels {c_j, c_j + 4}); H never leaves the register file.
+// A workgroup owns BM rows (i, c) of one subset and NW frames; it writes one (V x V) partial per (sample, subset, slot).
+// ------------------------------------------------------------------------------------------------------------------
+struct DadjArgs {
+  const float* dy;             // (N, Cout, T, V)
+  const unsigned short* wp;    // packed images [mblock][kchunk][plane][ks][tm][lane][8] (bf16)
+  const float* x;              // (N, C, T, V)
+  float* dpart;                // (N, 3, nslots, V, V)
+  int N, C, Cout, T, V;
+  int ntiles, nkc, nmb, nslots, gpc;   // gpc = row blocks per subset (C / BM)
+};
+
+struct DadjPackArgs {
+  const float* w;              // wcat (Cout, 3C)
+  unsigned short* wp;
+  int C3, Cout, nkc;
+};
+
+constexpr int KC = 32;         // dy channels per stage (two 16-deep MFMA steps)
+
+// one block per (mblock, kchunk) image: [plane][ks][tm][lane][8]; slot e of lane (row m, h) = channel kc*32 + ks*16 + h*8 + e
+template <int TM>
+__global__ void __launch_bounds__(256) dadj_pack_kernel(const DadjPackArgs p) {
+  constexpr int BM = TM * 32;
+  constexpr int PER_PLANE = 2 * TM * 64 * 8;
+  const int kc = blockIdx.x % p.nkc, mb = blockIdx.x / p.nkc;
+  unsigned short* dst = p.wp + (long)blockIdx.x * 3 * PER_PLANE;
+  for (int e = threadIdx.x; e < PER_PLANE / 2; e += 256) {
+    const int e2 = e & 3;
+    const int lane = (e >> 2) & 63;
+    const int r = e >> 8;
+    const int tm = r % TM, ks = r / TM;
+    const int h = lane >> 5, lr = lane & 31;
+    const int m = mb * BM + tm * 32 + lr;
+    float v[2];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      const int o = kc * KC + ks * 16 + h * 8 + 2 * e2 + q;
+      v[q] = (m < p.C3 && o < p.Cout) ? p.w[(long)o * p.C3 + m] : 0.f;
+    }
+    unsigned ph, pm, pl;
+    split_pair(v[0], v[1], ph, pm, pl);
+    const int o2 = ((ks * TM + tm) * 64 + lane) * 8 + 2 * e2;
+    *reinterpret_cast<unsigned*>(dst + 0 * PER_PLANE + o2) = ph;
+    *reinterpret_cast<unsigned*>(dst + 1 * PER_PLANE + o2) = pm;
+    *reinterpret_cast<unsigned*>(dst + 2 * PER_PLANE + o2) = pl;
+  }
+}
+
+template <int TM, int NW>
+__global__ void __launch_bounds__(NW * 64, 2) gcn_dadj_chain_kernel(const DadjArgs a) {
+  constexpr int NT = NW * 64, FT = NW, BM = TM * 32;
+  constexpr int A_IMG = 3 * 2 * TM * 1024;             // bytes of one stage's weight image
+  constexpr int A16 = A_IMG / 16;
+  constexpr int EA = (A16 + NT - 1) / NT;
+  constexpr int BI = (FT * 32 * 4 + NT - 1) / NT;      // staging items (position, 8-channel group) per thread
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int V = a.V, T = a.T;
+  const int PT = FT * V;                               // positions of the frame tile
+  const int B_IMG = 3 * 4 * PT * 16;                   // bytes: [plane][ks][h][pos][8]
+  unsigned char* abuf = smem;                          // [2][A_IMG]
+  unsigned char* bbuf = smem + 2 * A_IMG;              // [2][B_IMG]
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int lr = lane & 31, h = lane >> 5;
+  const int bid = xcd_remap(blockIdx.x, gridDim.x);
+  const int mbk = bid % a.nmb;
+  const int nt_id = bid / a.nmb;
+  const int n = nt_id / a.ntiles, tile_id = nt_id - n * a.ntiles;
+  const int m0 = mbk * BM;
+  const int isub = mbk / a.gpc, c0 = (mbk - isub * a.gpc) * BM;   // subset and first channel of this row block
+  const int t0 = tile_id * FT;
+  const int t = t0 + wave;
+  const bool fvalid = t < T;                           // wave-uniform
+  const int plen = min(FT, T - t0) * V;                // valid positions of the tile
+  const long P = (long)T * V;
+  const int S = a.nkc;
+
+  f32x16 acc[TM];
+#pragma unroll
+  for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+    for (int j = 0; j < 16; ++j) acc[tm][j] = 0.f;
+
+  u32x4 ra[EA];
+  float rb[BI][8];
+  const u32x4* wp4 = reinterpret_cast<const u32x4*>(a.wp) + (long)mbk * S * A16;
+  auto issue = [&](int s) __attribute__((always_inline)) {
+    const u32x4* src = wp4 + (long)s * A16;
+#pragma unroll
+    for (int u = 0; u < EA; ++u) ra[u] = src[min(tid + u * NT, A16 - 1)];
+#pragma unroll
+    for (int k = 0; k < BI; ++k) {
+      const int item = tid + k * NT;
+      const int og = item / PT, pos = item - og * PT;
+      const int o0 = s * KC + og * 8;
+      const float* src2 = a.dy + ((long)n * a.Cout) * P + (long)t0 * V + ((pos < plen) ? pos : 0);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) rb[k][e] = src2[(long)min(o0 + e, a.Cout - 1) * P];
+    }
+  };
+  auto commit = [&](int s) __attribute__((always_inline)) {
+    u32x4* dst = reinterpret_cast<u32x4*>(abuf + (s & 1) * A_IMG);
+#pragma unroll
+    for (int u = 0; u < EA; ++u)
+      if (tid + u * NT < A16) dst[tid + u * NT] = ra[u];
+    unsigned char* bd = bbuf + (s & 1) * B_IMG;
+#pragma unroll
+    for (int k = 0; k < BI; ++k) {
+      const int item = tid + k * NT;
+      const int og = item / PT, pos = item - og * PT;
+      const int o0 = s * KC + og * 8;
+      u32x4 ph, pm, pl;
+#pragma unroll
+      for (int e2 = 0; e2 < 4; ++e2) {
+        const float v0 = (pos < plen && o0 + 2 * e2 < a.Cout) ? rb[k][2 * e2] : 0.f;
+        const float v1 = (pos < plen && o0 + 2 * e2 + 1 < a.Cout) ? rb[k][2 * e2 + 1] : 0.f;
+        unsigned q0, q1, q2;
+        split_pair(v0, v1, q0, q1, q2);
+        ph[e2] = q0; pm[e2] = q1; pl[e2] = q2;
+      }
+      if (og < 4) {                                    // og = ks*2 + h
+        *reinterpret_cast<u32x4*>(bd + ((0 * 4 + og) * PT + pos) * 16) = ph;
+        *reinterpret_cast<u32x4*>(bd + ((1 * 4 + og) * PT + pos) * 16) = pm;
+        *reinterpret_cast<u32x4*>(bd + ((2 * 4 + og) * PT + pos) * 16) = pl;
+      }
+    }
+  };
+
+  issue(0);
+  commit(0);
+  if (S > 1) issue(1);
+  __syncthreads();
+  const int bpos = wave * V + min(lr, V - 1);          // this lane's column of the frame (padding lanes: clamped)
+  for (int s = 0; s < S; ++s) {
+    if (s + 1 < S) commit(s + 1);
+    if (s + 2 < S) issue(s + 2);
+    if (fvalid) {
+      const unsigned char* ab = abuf + (s & 1) * A_IMG + lane * 16;
+      const unsigned char* bb = bbuf + (s & 1) * B_IMG;
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        bf16x8 b[3];
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl)
+          b[pl] = *reinterpret_cast<const bf16x8*>(bb + (((pl * 2 + ks) * 2 + h) * PT + bpos) * 16);
+#pragma unroll
+        for (int tm = 0; tm < TM; ++tm) {
+          const bf16x8 a0 = *reinterpret_cast<const bf16x8*>(ab + ((0 * 2 + ks) * TM + tm) * 1024);
+          const bf16x8 a1 = *reinterpret_cast<const bf16x8*>(ab + ((1 * 2 + ks) * TM + tm) * 1024);
+          const bf16x8 a2 = *reinterpret_cast<const bf16x8*>(ab + ((2 * 2 + ks) * TM + tm) * 1024);
+          acc[tm] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, b[0], acc[tm], 0, 0, 0);
+          acc[tm] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b[2], acc[tm], 0, 0, 0);
+          acc[tm] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b[1], acc[tm], 0, 0, 0);
+          acc[tm] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b[0], acc[tm], 0, 0, 0);
+          acc[tm] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b[1], acc[tm], 0, 0, 0);
+          acc[tm] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b[0], acc[tm], 0, 0, 0);
+        }
+      }
+    }
+    __syncthreads();
+  }
+
+  // ---- reduction against x: d[u][v] += sum_c x[c][t,u] * H[c][v]; the x operands come straight from global/L2
+  // (row u = lane, k-pair of step j = channels c_j + 4h), one 16-load batch per 32-channel tile ----
+  f32x16 d;
+#pragma unroll
+  for (int j = 0; j < 16; ++j) d[j] = 0.f;
+  if (fvalid) {
+    const float* xr = a.x + ((long)n * a.C + c0) * P + (long)t * V + min(lr, V - 1);
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm) {
+      float xa[16];
+#pragma unroll
+      for (int j = 0; j < 16; ++j) {
+        const int c = tm * 32 + (j & 3) + 8 * (j >> 2) + 4 * h;
+        xa[j] = xr[(long)min(c0 + c, a.C - 1) * P - (long)c0 * P];
+      }
+#pragma unroll
+      for (int j = 0; j < 16; ++j) d = mfma32((lr < V) ? xa[j] : 0.f, acc[tm][j], d);
+    }
+  }
+  // ---- sum the NW frames of the tile and store the slot ----
+  const int VV = V * V;
+  float* red = reinterpret_cast<float*>(smem);         // [NW][VV]; the loop's final barrier freed LDS
+#pragma unroll
+  for (int j = 0; j < 16; ++j) {
+    const int u = mfma_row(j, h);
+    if (u < V && lr < V) red[wave * VV + u * V + lr] = d[j];
+  }
+  __syncthreads();
+  const int slot = tile_id * a.gpc + (mbk - isub * a.gpc);
+  float* dst = a.dpart + (((long)n * 3 + isub) * a.nslots + slot) * VV;
+  for (int e = tid; e < VV; e += NT) {
+    float sum = 0.f;
+#pragma unroll
+    for (int w2 = 0; w2 < NW; ++w2) sum += red[w2 * VV + e];
+    dst[e] = sum;
+  }
+}
+
+template <int TM, int NW>
+int dadj_chain_launch(DadjArgs a, const float* wcat, void* ws, size_t ws_bytes, hipStream_t stream) {
+  constexpr int BM = TM * 32, FT = NW;
+  a.ntiles = (a.T + FT - 1) / FT;
+  a.nkc = (a.Cout + KC - 1) / KC;
+  a.gpc = a.C / BM;
+  a.nmb = 3 * a.gpc;
+  a.nslots = a.ntiles * a.gpc;
+  const size_t a_img = (size_t)3 * 2 * TM * 1024;
+  const size_t b_img = (size_t)3 * 4 * FT * a.V * 16;
+  size_t smem_bytes = 2 * a_img + 2 * b_img;
+  const size_t epi = (size_t)NW * a.V * a.V * 4;
+  if (epi > smem_bytes) smem_bytes = epi;
+  if (smem_bytes > 160 * 1024) return AGCN_ERR_UNSUPPORTED;
+  const size_t pack_bytes = (size_t)a.nmb * a.nkc * a_img;
+  if (pack_bytes > ws_bytes) return AGCN_ERR_WORKSPACE;
+  a.wp = (const unsigned short*)ws;
+  DadjPackArgs pk;
+  pk.w = wcat; pk.wp = (unsigned short*)ws; pk.C3 = 3 * a.C; pk.Cout = a.Cout; pk.nkc = a.nkc;
+  hipLaunchKernelGGL((dadj_pack_kernel<TM>), dim3(a.nmb * a.nkc), dim3(256), 0, stream, pk);
+  int rc = agcn_check_launch();
+  if (rc) return rc;
+  auto kern = gcn_dadj_chain_kernel<TM, NW>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e != hipSuccess) return (int)e;
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(kern, dim3((unsigned)(a.N * a.ntiles * a.nmb)), dim3(NW * 64), smem_bytes, stream, a);
+  return agcn_check_launch();
+}
+
 }  // namespace
 
 // rows per block: 128 when M is a multiple of 128, else 64
@@ -446,4 +687,26 @@ int agcn_gcn_chain(int mode, const float* in, const float* adj, const float* wca
   }
   if (chain_tm(a.M) == 4) return chain_dispatch_vs<4, 4>(a, wcat, sa_m, sa_i, sa_c, ws, ws_bytes, stream);
   return chain_dispatch_vs<2, 4>(a, wcat, sa_m, sa_i, sa_c, ws, ws_bytes, stream);
+}
+
+// ---- adjacency gradient (gcn_dadj_chain_kernel): C a multiple of 64; row block 128 when C is a multiple of 128 ----
+constexpr int DADJ_NW = 8;
+bool agcn_gcn_dadj_chain_supported(int C, int V) { return C >= 64 && C % 64 == 0 && V <= 32; }
+
+int agcn_gcn_dadj_chain_slots(int C, int T) {
+  const int bm = (C % 128 == 0) ? 128 : 64;
+  return ((T + DADJ_NW - 1) / DADJ_NW) * (C / bm);
+}
+
+size_t agcn_gcn_dadj_chain_workspace(int C, int Cout) {
+  const int bm = (C % 128 == 0) ? 128 : 64;
+  return (size_t)(3 * C / bm) * ((Cout + KC - 1) / KC) * 3 * 2 * (bm / 32) * 1024;
+}
+
+int agcn_gcn_dadj_chain(const float* dy, const float* wcat, const float* x, float* dadj_part, void* ws, size_t ws_bytes,
+                        int N, int C, int Cout, int T, int V, hipStream_t stream) {
+  DadjArgs a = {};
+  a.dy = dy; a.x = x; a.dpart = dadj_part; a.N = N; a.C = C; a.Cout = Cout; a.T = T; a.V = V;
+  if (C % 128 == 0) return dadj_chain_launch<4, DADJ_NW>(a, wcat, ws, ws_bytes, stream);
+  return dadj_chain_launch<2, DADJ_NW>(a, wcat, ws, ws_bytes, stream);
 }

@@ -19,6 +19,12 @@ import sys
 import numpy as np
 import torch
 
+# Model-level gradient conditioning band: an fp32 evaluation in another summation order reproduces the reference's
+# activations to 1-3e-6 relative (measured), so the band is taken at 2e-6, over 8 draws (3 draws at 1e-6 under-sampled
+# which ReLU-kink elements flip: a 3e-6 input perturbation of a correct fp32 run moved 13 tensors past that band).
+MODEL_SENS_SAMPLES = 8
+MODEL_SENS_EPS = 2e-6
+
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(os.path.dirname(HERE))
 REF = '/root/reference'
@@ -204,14 +210,14 @@ def make_model(ref, name, n, v, num_class, graph, seed, stress, t):
     # Conditioning of the gradients: the network has ~1e6 ReLU inputs per layer, a few of them within 1e-6 of
     # the kink; ANY perturbation of that size (fp32 rounding, another summation order) flips their masks and
     # moves some parameter gradients by ~1e-2 of max|g|.  Measure it with the reference itself (fp64, inputs
-    # perturbed by 1e-6 relative) and store the per-tensor band next to the gradients.
+    # perturbed by MODEL_SENS_EPS relative, MODEL_SENS_SAMPLES draws) and store the per-tensor band next to the gradients.
     g64 = {k: p.grad.detach().clone() for k, p in model64.named_parameters()}
     sens = {k: 0.0 for k in g64}
     prng = torch.Generator().manual_seed(seed)
-    for _ in range(3):
+    for _ in range(MODEL_SENS_SAMPLES):
         model64.zero_grad()
         xp = torch.from_numpy(xn).double()
-        xp = xp * (1.0 + 1e-6 * torch.randn(xp.shape, generator=prng, dtype=torch.float64))
+        xp = xp * (1.0 + MODEL_SENS_EPS * torch.randn(xp.shape, generator=prng, dtype=torch.float64))
         torch.nn.functional.cross_entropy(model64(xp), torch.from_numpy(lab)).backward()
         for k, p in model64.named_parameters():
             d = float((p.grad - g64[k]).abs().max() / max(1e-300, float(g64[k].abs().max())))
@@ -383,10 +389,10 @@ def make_aagcn_model(ref, name='am_ntu_b1_t64', n=1, v=25, num_class=60, seed=50
     g64 = {k: p.grad.detach().clone() for k, p in model64.named_parameters()}
     sens = {k: 0.0 for k in g64}
     prng = torch.Generator().manual_seed(seed)
-    for _ in range(3):
+    for _ in range(MODEL_SENS_SAMPLES):
         model64.zero_grad()
         xp = torch.from_numpy(xn).double()
-        xp = xp * (1.0 + 1e-6 * torch.randn(xp.shape, generator=prng, dtype=torch.float64))
+        xp = xp * (1.0 + MODEL_SENS_EPS * torch.randn(xp.shape, generator=prng, dtype=torch.float64))
         torch.nn.functional.cross_entropy(model64(xp)[0], torch.from_numpy(lab)).backward()
         for k, p in model64.named_parameters():
             sens[k] = max(sens[k], float((p.grad - g64[k]).abs().max() / max(1e-300, float(g64[k].abs().max()))))
