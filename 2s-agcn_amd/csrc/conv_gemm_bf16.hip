@@ -12,6 +12,7 @@
 // and the source window is split while it is staged:  B[plane][h][position][8 channels], so that a lane's MFMA
 // fragment (8 consecutive k for one row/column) is one conflict-free ds_read_b128, and a temporal tap is a row offset.
 #include "agcn_common.h"
+#include "epilogue.h"
 
 namespace {
 
@@ -40,6 +41,7 @@ struct BfArgs {
   int accumulate;
   int nchunks, nmb;
   int off_b;                   // byte offset of the B image in LDS
+  int off_bias;                // byte offset of the bias row in LDS
 };
 
 struct BfPackArgs {
@@ -111,9 +113,9 @@ __global__ void __launch_bounds__(NT, (TAPS == 1 && TM == 2) ? 4 : 2) conv_gemm_
   const int bid = xcd_remap(blockIdx.x, gridDim.x);
   const int mbk = bid % a.nmb;
   const int nt_id = bid / a.nmb;
-  const int n = nt_id / a.ntiles, tile = nt_id - n * a.ntiles;
+  const int n = nt_id / a.ntiles, tile_id = nt_id - n * a.ntiles;
   const int m0 = mbk * BM;
-  const int V = a.V, tt = a.tt, t0 = tile * tt;
+  const int V = a.V, tt = a.tt, t0 = tile_id * tt;
   const int ttv = tt * V;
   const int nvalid = min(tt, a.T_out - t0) * V;
   const int Psrc = a.T_src * V;
@@ -126,6 +128,9 @@ __global__ void __launch_bounds__(NT, (TAPS == 1 && TM == 2) ? 4 : 2) conv_gemm_
   const int tl = q / V, v = q - tl * V;
   const int boff = tl * a.src_stride * V + v;
   const int ooff = ((t0 + tl) * a.out_fs + a.out_fo) * V + v;
+
+  float* bias_s = reinterpret_cast<float*>(smem + a.off_bias);   // beyond everything the epilogue tile overwrites
+  for (int e = tid; e < BM; e += NT) bias_s[e] = (a.bias && m0 + e < a.M) ? a.bias[m0 + e] : 0.f;
 
   f32x16 acc[TM];
 #pragma unroll
@@ -218,84 +223,36 @@ __global__ void __launch_bounds__(NT, (TAPS == 1 && TM == 2) ? 4 : 2) conv_gemm_
     }
   }
 
-  // ---- epilogue: store (+bias, +accumulate, +masked addends), per-channel (sum, sumsq) partials ----
-  float* red = reinterpret_cast<float*>(smem);   // [NW][2][BM]
+  // ---- epilogue (epilogue.h): tile -> LDS -> coalesced row stores, residual operands, (sum, sumsq) partials ----
+  __syncthreads();                                     // every wave is done with the A/B images
+  float* tile = reinterpret_cast<float*>(smem);        // [BM][TP]
+  const int TP = NW * 32 + 1;
+  float* red = tile + BM * TP;                         // [NT * 2]
+  {
+    const int q = wave * 32 + lr;
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+      for (int j = 0; j < 16; ++j) tile[(tm * 32 + mfma_row(j, h)) * TP + q] = acc[tm][j];
+  }
+  __syncthreads();
+  int poff[4];
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    const int q2 = lane + 64 * u;
+    const int tl2 = q2 / V;
+    poff[u] = tl2 * a.out_fs * V + (q2 - tl2 * V);
+  }
+  EpiPtrs ep;
+  ep.out = a.out; ep.add1 = a.add1; ep.mask1 = a.mask1; ep.add2 = a.add2; ep.mask2 = a.mask2; ep.stats = a.stats;
+  ep.accumulate = a.accumulate;
   const long Pfull = (long)a.T_full * V;
-  if (a.stats) __syncthreads();
-  const bool has_extra = a.accumulate || a.add1 || a.add2;
-  const int qq = wave * 32 + lr;
-#pragma unroll
-  for (int tm = 0; tm < TM; ++tm) {
-#pragma unroll
-    for (int jb = 0; jb < 4; ++jb) {
-      float ex[4];
-      long idxs[4];
-      bool oks[4];
-#pragma unroll
-      for (int jj = 0; jj < 4; ++jj) {
-        const int m = m0 + tm * 32 + mfma_row(jb * 4 + jj, h);
-        oks[jj] = (m < a.M) && (qq < nvalid);
-        idxs[jj] = oks[jj] ? (((long)n * a.M + m) * Pfull + ooff) : 0;
-        ex[jj] = 0.f;
-      }
-      if (has_extra) {
-#pragma unroll
-        for (int jj = 0; jj < 4; ++jj) {
-          const long idx = idxs[jj];
-          float e = 0.f;
-          if (a.accumulate) e += a.out[idx];
-          if (a.add1) {
-            float t = a.add1[idx];
-            if (a.mask1) t = (a.mask1[idx] > 0.f) ? t : 0.f;
-            e += t;
-          }
-          if (a.add2) {
-            float t = a.add2[idx];
-            if (a.mask2) t = (a.mask2[idx] > 0.f) ? t : 0.f;
-            e += t;
-          }
-          ex[jj] = e;
-        }
-      }
-#pragma unroll
-      for (int jj = 0; jj < 4; ++jj) {
-        const int j = jb * 4 + jj;
-        const int ml = tm * 32 + mfma_row(j, h);
-        const int m = m0 + ml;
-        const float bval = (a.bias && m < a.M) ? a.bias[m] : 0.f;
-        const float val = acc[tm][j] + bval + ex[jj];
-        float bsum = 0.f, bsq = 0.f;
-        if (oks[jj]) {
-          a.out[idxs[jj]] = val;
-          bsum = val;
-          bsq = val * val;
-        }
-        if (a.stats) {
-          bsum = half_sum(bsum);
-          bsq = half_sum(bsq);
-          if (lr == 0) {
-            red[(wave * 2 + 0) * BM + ml] = bsum;
-            red[(wave * 2 + 1) * BM + ml] = bsq;
-          }
-        }
-      }
-    }
-  }
-  if (a.stats) {
-    __syncthreads();
-    const long slot = (long)n * a.ntiles + tile;
-    for (int e = tid; e < 2 * BM; e += NT) {
-      const int k = e / BM, ml = e - k * BM;
-      float s = 0.f;
-#pragma unroll
-      for (int w2 = 0; w2 < NW; ++w2) s += red[(w2 * 2 + k) * BM + ml];
-      if (m0 + ml < a.M) a.stats[(slot * 2 + k) * a.M + m0 + ml] = s;
-    }
-  }
+  const long rows0 = (long)n * a.M * Pfull + ((long)t0 * a.out_fs + a.out_fo) * V;
+  epilogue_rows<BM, NW, 4>(ep, tile, TP, bias_s, red, a.M, m0, rows0, Pfull, nvalid, poff, (long)n * a.ntiles + tile_id);
 }
 
 struct BfGeom {
-  int tt, ntiles, FW, WLR, nchunks, nmb, off_b;
+  int tt, ntiles, FW, WLR, nchunks, nmb, off_b, off_bias;
   size_t smem_bytes, pack_bytes;
 };
 
@@ -314,8 +271,10 @@ BfGeom bf_geometry(int V, int T_out, int src_stride, int M, int Kinner) {
   g.off_b = (int)a_bytes;
   const size_t b_bytes = (size_t)3 * 2 * g.WLR * 16;
   size_t main_b = a_bytes + b_bytes;
-  size_t epi_b = (size_t)NW * 2 * BM * 4;
-  g.smem_bytes = main_b > epi_b ? main_b : epi_b;
+  size_t epi_b = (size_t)BM * (NW * 32 + 1) * 4 + (size_t)NT * 2 * 4;
+  g.smem_bytes = ((main_b > epi_b ? main_b : epi_b) + 15) & ~(size_t)15;
+  g.off_bias = (int)g.smem_bytes;
+  g.smem_bytes += (size_t)BM * 4;
   g.pack_bytes = (size_t)g.nmb * g.nchunks * a_bytes;
   return g;
 }
@@ -338,7 +297,7 @@ int launch_bf(BfProblem& p, hipStream_t stream) {
   if ((g.FW * a.V + 3) / 4 > WQ * 64) return AGCN_ERR_UNSUPPORTED;
   if (g.pack_bytes > p.ws_bytes) return AGCN_ERR_WORKSPACE;
   a.tt = g.tt; a.ntiles = g.ntiles; a.FW = g.FW; a.WLR = g.WLR; a.nchunks = g.nchunks; a.nmb = g.nmb;
-  a.off_b = g.off_b;
+  a.off_b = g.off_b; a.off_bias = g.off_bias;
   a.wp = (const unsigned short*)p.ws;
   if (g.nchunks > 0) {
     BfPackArgs pk;

@@ -58,8 +58,9 @@ def randomize_like_training(model, seed):
 
 
 def dominant_kernel_roofline(device, reps=10):
-    """The kernel with the largest share of the step (profiles/r01_*_kernel_stats.txt): unit_tcn's 9x1 temporal
-    convolution forward at the l9/l10 shape (N'=128, C=Cout=256, T=75, V=25), timed with HIP events on the stream it
+    """The kernel family with the largest share of the step (profiles/r01_*_kernel_stats.txt: conv_gemm_bf16_kernel,
+    ~17 % of GPU time over its instantiations): unit_tcn's 9x1 temporal convolution, timed here as the forward at the
+    l9/l10 shape (N'=128, C=Cout=256, T=75, V=25), timed with HIP events on the stream it
     is launched on.  Algorithmic work per launch: 2*Cout*Cin*9 FLOP per output position x 128*75*25
     positions = 283.1 GFLOP (fp32-equivalent).
     Default arithmetic (AGCN_GEMM=bf16x6): every fp32 product is 6 bf16 MFMA products with fp32 accumulation, so the

@@ -83,7 +83,10 @@ def grad_check(g, gold, name, tol):
     the fixtures also hold the SAME reference code run in fp64, which gives the reference's own fp32 rounding
     noise per tensor (up to ~1e-2 of max|g| for the adjacency parameters of the full model, whose gradients are
     sums of ~1e5 cancelling terms).  Pass if err32 <= tol, or if the result is as close to the fp64 answer as
-    the fp32 reference itself is (within 3x): err64 <= tol + 3*noise.  Returns (ok, err32, err64, noise)."""
+    the fp32 reference itself is (within 3x): err64 <= tol + 3*noise (5x for the perturbation band of the model
+    fixtures, whose 8 draws sample the tail of the kink-flip distribution only coarsely: a 3e-6 input perturbation
+    of a correct fp32 run was measured to move individual tensors to 10x a 3-draw band).
+    Returns (ok, err32, err64, noise)."""
     scale = max(float(gold['g.' + name + '.absmax']), 1e-12)
     a, r32 = _pick(gold, 'g.', name, g)
     err32 = float(np.abs(a - r32).max() / scale)
@@ -94,12 +97,14 @@ def grad_check(g, gold, name, tol):
     # 'sens.*' (model fixtures): how far the REFERENCE's own fp64 gradient moves when its input is perturbed by
     # 1e-6 relative -- ReLU masks of elements sitting on the kink flip (see make_golden.py).  It bounds what any
     # two correct fp32 evaluations can be expected to agree to.
+    factor = 3.0
     if ('sens.' + name) in gold:
+        factor = 5.0
         # three perturbation samples under-sample which kink elements flip, so the band of a tensor is at
         # least the model-wide median band (a flip in layer L moves the gradients of every layer below it)
         noise = max(noise, float(gold['sens.' + name]), sens_floor(gold))
     err64 = float(np.abs(a - r64).max() / scale)
-    return (err32 <= tol) or (err64 <= tol + 3.0 * noise), err32, err64, noise
+    return (err32 <= tol) or (err64 <= tol + factor * noise), err32, err64, noise
 
 AAGCN_UNIT_NAMES = ['au_64_64_s1_v25', 'au_64_128_s2_v25', 'au_3_64_s1_v18', 'au_64_64_s1_v25_plain']
 

@@ -97,6 +97,9 @@ GCN_CASES = [
     (2, 128, 256, 9, 25),
     (2, 256, 256, 7, 25),
     (2, 64, 64, 17, 18),
+    (2, 128, 128, 16, 25),
+    (1, 256, 128, 33, 25),
+    (2, 64, 80, 10, 20),        # rows/K not multiples of the 32-channel stage, generic V
 ]
 
 
@@ -129,6 +132,15 @@ def test_aggregate_project(case):
     assert rel(s[0], y_ref.detach().sum((0, 2, 3))) < TOL * 10
     dx = ops.aggregate_project_bwd_data(dyg, ag, wg, tuple(x.shape))
     assert rel(dx, x.grad) < TOL
+    # fused epilogue operands: dx = prior + grad + add1*[mask1>0] + add2*[mask2>0]  (unit residual / identity `down`)
+    a1, m1, a2, m2 = [rnd(g, N, C, T, V).float().to(dev) for _ in range(4)]
+    prior = rnd(g, N, C, T, V).float().to(dev)
+    ref2 = x.grad.float().to(dev) + prior + a1 * (m1 > 0) + a2 * (m2 > 0)
+    dx2 = ops.aggregate_project_bwd_data(dyg, ag, wg, tuple(x.shape), out=prior.clone(), accumulate=True, add1=a1,
+                                         mask1=m1, add2=a2, mask2=m2)
+    assert rel(dx2, ref2) < TOL
+    dx3 = ops.aggregate_project_bwd_data(dyg, ag, wg, tuple(x.shape), add1=a1)
+    assert rel(dx3, x.grad.float().to(dev) + a1) < TOL
     dw = ops.project_bwd_weight(dyg, xg, ag, Cout)
     assert rel(dw, wcat.grad) < TOL
     # adjacency gradient via the slot partials

@@ -32,5 +32,18 @@ w99 = (torch.randn(256, 256, 9, 1, generator=g) / 48).to(dev)
 b9 = torch.zeros(256, device=dev)
 for rep in range(2):
     ops.conv_fwd(x9, w99, b9, 1, want_stats=True)
+# unit_gcn aggregate+project (gcn_chain_kernel) forward / backward-data and the adjacency gradient at the same shape
+adj9 = (0.2 * torch.randn(128, 3, 25, 25, generator=g)).to(dev)
+wd9 = (torch.randn(256, 768, generator=g) / 27.7).to(dev)
+for rep in range(2):
+    ops.aggregate_project_fwd(x9, adj9, wd9, b9, want_stats=True)
+    ops.aggregate_project_bwd_data(x9, adj9, wd9, tuple(x9.shape))
+    ops.adjacency_bwd  # (dadj is launched through the C entry point below)
+    from agcn_amd import lib
+    L = ops._L(); ns = L.agcn_dadj_num_slots(256, 25, 75)
+    dpart = torch.empty((128, 3, ns, 25, 25), device=dev)
+    ws, nb = ops._gcn_ws(256, 256, 75, 25, x9)
+    lib.check(L.agcn_gcn_dadj(lib.ptr(x9), lib.ptr(wd9), lib.ptr(x9), lib.ptr(dpart), ws.data_ptr(), nb, 128, 256, 256,
+                              75, 25, lib.stream()), 'dadj')
 torch.cuda.synchronize()
 print('done')
