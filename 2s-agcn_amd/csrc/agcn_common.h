@@ -71,6 +71,12 @@ size_t agcn_gcn_dadj_chain_workspace(int C, int Cout);
 int agcn_gcn_dadj_chain(const float* dy, const float* wcat, const float* x, float* dadj_part, void* ws, size_t ws_bytes,
                         int N, int C, int Cout, int T, int V, hipStream_t stream);
 
+// split-bf16 weight gradients of the tap-free contractions (wgrad_chain.hip): partial slabs only, reduced by the caller
+bool agcn_wgrad_chain_supported(int M, int C, int V);
+size_t agcn_wgrad_chain_workspace(int agg, int N, int M, int C, int V, int T_out);
+int agcn_wgrad_chain(int agg, const float* dy, const float* x, const float* adj, void* ws, size_t ws_bytes, int* nslabs,
+                     int N, int M, int C, int V, int T_src, int T_out, int stride, hipStream_t s);
+
 // GEMM arithmetic of the 9x1 temporal convolutions (forward / backward-data): 3 = bf16x6 (default: fp32-equivalent
 // accuracy, measured), 0 = f32 MFMA, 2 = bf16x3 (~5e-6 per GEMM; does NOT hold the 1e-4 parity bar end to end).
 // Chosen once per process from the environment variable AGCN_GEMM (bf16x6 | f32 | bf16x3).

@@ -332,6 +332,27 @@ size_t ws_wgrad(int N, int M, int C, int V, int T_out, int stride, long wsize) {
   return (size_t)g.nslabs * wsize * 4;
 }
 
+// split-bf16 path (wgrad_chain.hip) + the same fixed-order slab reduction
+int chain_wgrad_and_reduce(int agg, const WgradArgs& a, float* dw, void* ws, size_t ws_bytes, hipStream_t stream) {
+  int nslabs = 0;
+  int rc = agcn_wgrad_chain(agg, a.dy, a.in, a.adj, ws, ws_bytes, &nslabs, a.N, a.M, a.C, a.V, a.T_src, a.T_out,
+                            a.stride, stream);
+  if (rc) return rc;
+  const int threads = 256;
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((a.wsize + threads - 1) / threads)), dim3(threads), 0,
+                     stream, (const float*)ws, dw, a.wsize, nslabs, a.M, a.C, a.so_m, a.so_t, a.so_c);
+  return agcn_check_launch();
+}
+
+inline bool chain_wgrad_enabled() {
+  static int v = -1;
+  if (v < 0) {
+    const char* e = getenv("AGCN_WGRAD_BF16");
+    v = (e && atoi(e) == 0) ? 0 : 1;
+  }
+  return v == 1 && agcn_gemm_precision() == 3;
+}
+
 }  // namespace
 
 extern "C" {
@@ -345,8 +366,13 @@ size_t agcn_conv_bwd_weight_workspace(int N, int Cin, int Cout, int T, int V, in
     if (Cout % 128 == 0) return ws_wgrad<9, 0, 4, 1, 2, false>(N, Cout, Cin, V, T_out, stride, wsize);
     return ws_wgrad<9, 0, 2, 2, 2, false>(N, Cout, Cin, V, T_out, stride, wsize);
   }
-  if (Cout % 128 == 0) return ws_wgrad<1, 0, 4, 2, 1, false>(N, Cout, Cin, V, T_out, stride, wsize);
-  return ws_wgrad<1, 0, 2, 2, 2, true>(N, Cout, Cin, V, T_out, stride, wsize);
+  size_t b = (Cout % 128 == 0) ? ws_wgrad<1, 0, 4, 2, 1, false>(N, Cout, Cin, V, T_out, stride, wsize)
+                              : ws_wgrad<1, 0, 2, 2, 2, true>(N, Cout, Cin, V, T_out, stride, wsize);
+  if (agcn_wgrad_chain_supported(Cout, Cin, V)) {
+    const size_t t = agcn_wgrad_chain_workspace(0, N, Cout, Cin, V, T_out);
+    if (t > b) b = t;
+  }
+  return b;
 }
 
 // dw[o][c][k] = sum_{n,t,v} dy[n][o][t,v] * x[n][c][(t*stride + k - pad), v]
@@ -369,14 +395,21 @@ int agcn_conv_bwd_weight(const float* dy, const float* x, float* dw, void* works
     if (Cout % 128 == 0) return launch_wgrad<9, 0, 4, 1, 2, false, 7>(a, dw, workspace, workspace_bytes, s);
     return launch_wgrad<9, 0, 2, 2, 2, false, 7>(a, dw, workspace, workspace_bytes, s);
   }
+  if (chain_wgrad_enabled() && agcn_wgrad_chain_supported(Cout, Cin, V))
+    return chain_wgrad_and_reduce(0, a, dw, workspace, workspace_bytes, s);
   if (Cout % 128 == 0) return launch_wgrad<1, 0, 4, 2, 1, false, 4>(a, dw, workspace, workspace_bytes, s);
   return launch_wgrad<1, 0, 2, 2, 2, true, 4>(a, dw, workspace, workspace_bytes, s);
 }
 
 size_t agcn_gcn_project_bwd_weight_workspace(int N, int C, int Cout, int T, int V) {
   const long wsize = 3L * Cout * C;
-  if (Cout % 128 == 0) return ws_wgrad<1, 1, 4, 2, 1, false>(N, Cout, C, V, T, 1, wsize);
-  return ws_wgrad<1, 1, 2, 2, 2, true>(N, Cout, C, V, T, 1, wsize);
+  size_t b = (Cout % 128 == 0) ? ws_wgrad<1, 1, 4, 2, 1, false>(N, Cout, C, V, T, 1, wsize)
+                              : ws_wgrad<1, 1, 2, 2, 2, true>(N, Cout, C, V, T, 1, wsize);
+  if (agcn_wgrad_chain_supported(Cout, C, V)) {
+    const size_t t = agcn_wgrad_chain_workspace(1, N, Cout, C, V, T);
+    if (t > b) b = t;
+  }
+  return b;
 }
 
 // dwcat[o][i*C+c] = sum_{n,t,v} dy[n][o][t,v] * sum_u x[n][c][t,u] adj[n][i][u][v]
@@ -388,6 +421,8 @@ int agcn_gcn_project_bwd_weight(const float* dy, const float* x, const float* ad
   a.dy = dy; a.in = x; a.adj = adj; a.N = N; a.M = Cout; a.C = C; a.V = V; a.T_src = T; a.T_out = T; a.stride = 1;
   a.so_m = 3L * C; a.so_t = C; a.so_c = 1; a.wsize = 3L * Cout * C;
   hipStream_t s = (hipStream_t)stream;
+  if (chain_wgrad_enabled() && agcn_wgrad_chain_supported(Cout, C, V))
+    return chain_wgrad_and_reduce(1, a, dwcat, workspace, workspace_bytes, s);
   if (Cout % 128 == 0) return launch_wgrad<1, 1, 4, 2, 1, false, 2>(a, dwcat, workspace, workspace_bytes, s);
   return launch_wgrad<1, 1, 2, 2, 2, true, 2>(a, dwcat, workspace, workspace_bytes, s);
 }
