@@ -133,7 +133,7 @@ bn_bwd_reduce_kernel(const float* __restrict__ dout, const float* __restrict__ m
 }
 
 // coef[0..2][C] = (A1,B1,C1) with dy1 = A1*dz + B1*y1 + C1 ; coef[3..5][C] same for branch 2
-__global__ void bn_bwd_finalize_kernel(const float* __restrict__ part, int N, int C, double count,
+__global__ void bn_bwd_finalize_kernel(const float* __restrict__ part, int N, int C, double count, float pscale,
                                        const float* __restrict__ gamma1, const float* __restrict__ mean1,
                                        const float* __restrict__ invstd1, const float* __restrict__ gamma2,
                                        const float* __restrict__ mean2, const float* __restrict__ invstd2,
@@ -155,8 +155,8 @@ __global__ void bn_bwd_finalize_kernel(const float* __restrict__ part, int N, in
     coef[0 * C + c] = (float)k;
     coef[1 * C + c] = (float)(-k * is * sxh / count);
     coef[2 * C + c] = (float)(-k * s0 / count + k * is * mu * sxh / count);
-    dgamma1[c] = (float)sxh;
-    dbeta1[c] = (float)s0;
+    dgamma1[c] = (float)sxh * pscale;
+    dbeta1[c] = (float)s0 * pscale;
   }
   if (gamma2) {
     const double is = invstd2[c], mu = mean2[c], g = gamma2[c];
@@ -165,8 +165,8 @@ __global__ void bn_bwd_finalize_kernel(const float* __restrict__ part, int N, in
     coef[3 * C + c] = (float)k;
     coef[4 * C + c] = (float)(-k * is * sxh / count);
     coef[5 * C + c] = (float)(-k * s0 / count + k * is * mu * sxh / count);
-    dgamma2[c] = (float)sxh;
-    dbeta2[c] = (float)s0;
+    dgamma2[c] = (float)sxh * pscale;
+    dbeta2[c] = (float)s0 * pscale;
   }
 }
 
@@ -284,24 +284,36 @@ int agcn_bn_act_fwd(const float* y1, const float* scale1, const float* shift1, c
 }
 
 // Backward of out = relu(bn1(y1) + [bn2(y2)] + ...): dz = dout*(mask>0) (mask may be null);
-// dy1 = A1*dz + B1*y1 + C1 (train-mode BN backward), same for branch 2.  part: (N*C*3) scratch, coef: (6*C) scratch.
-int agcn_bn_bwd(const float* dout, const float* mask, const float* y1, const float* gamma1, const float* mean1,
-                const float* invstd1, const float* y2, const float* gamma2, const float* mean2, const float* invstd2,
-                float* part, float* coef, float* dy1, float* dgamma1, float* dbeta1, float* dy2, float* dgamma2,
-                float* dbeta2, int N, int C, int P, void* stream) {
-  if (!dout || !y1 || !gamma1 || !mean1 || !invstd1 || !part || !coef || !dy1 || !dgamma1 || !dbeta1) return AGCN_ERR_ARG;
+// dy1 = A1*dz + B1*y1 + C1 (train-mode BN backward), same for branch 2.  Two stages so that a synchronised BatchNorm
+// (reference DDP + SyncBatchNorm, utils/processor.py:295) can all-reduce the per-channel sums in between:
+//   agcn_bn_bwd_reduce: part[(n*C + c)*3 + k] = per-row (sum dz, sum dz*y1, sum dz*y2)
+//   agcn_bn_bwd_apply : sums `nrows` rows of part per channel (fixed order), then the coefficients over `count`
+//                       elements and the element-wise pass; dgamma/dbeta are multiplied by param_grad_scale
+//                       (1/world when the sums are global, so that the gradient all-reduce average restores them).
+int agcn_bn_bwd_reduce(const float* dout, const float* mask, const float* y1, const float* y2, float* part, int N, int C,
+                       int P, void* stream) {
+  if (!dout || !y1 || !part || N <= 0 || C <= 0 || P <= 0) return AGCN_ERR_ARG;
+  hipStream_t s = (hipStream_t)stream;
+  if (y2) hipLaunchKernelGGL(bn_bwd_reduce_kernel<true>, dim3(N * C), dim3(256), 0, s, dout, mask, y1, y2, part, P);
+  else hipLaunchKernelGGL(bn_bwd_reduce_kernel<false>, dim3(N * C), dim3(256), 0, s, dout, mask, y1, y2, part, P);
+  return agcn_check_launch();
+}
+
+int agcn_bn_bwd_apply(const float* part, int nrows, double count, float param_grad_scale, const float* dout,
+                      const float* mask, const float* y1, const float* gamma1, const float* mean1, const float* invstd1,
+                      const float* y2, const float* gamma2, const float* mean2, const float* invstd2, float* coef,
+                      float* dy1, float* dgamma1, float* dbeta1, float* dy2, float* dgamma2, float* dbeta2, int N, int C,
+                      int P, void* stream) {
+  if (!part || !dout || !y1 || !gamma1 || !mean1 || !invstd1 || !coef || !dy1 || !dgamma1 || !dbeta1 || nrows <= 0)
+    return AGCN_ERR_ARG;
   if (y2 && (!gamma2 || !mean2 || !invstd2 || !dy2 || !dgamma2 || !dbeta2)) return AGCN_ERR_ARG;
   const long total = (long)N * C * P;
   if (total % 4 != 0 || total / 4 > 0x7fffffffL) return AGCN_ERR_UNSUPPORTED;
   hipStream_t s = (hipStream_t)stream;
-  if (y2) hipLaunchKernelGGL(bn_bwd_reduce_kernel<true>, dim3(N * C), dim3(256), 0, s, dout, mask, y1, y2, part, P);
-  else hipLaunchKernelGGL(bn_bwd_reduce_kernel<false>, dim3(N * C), dim3(256), 0, s, dout, mask, y1, y2, part, P);
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 63) / 64), dim3(64), 0, s, part, nrows, C, count,
+                     param_grad_scale, gamma1, mean1, invstd1, y2 ? gamma2 : nullptr, mean2, invstd2, coef, dgamma1,
+                     dbeta1, dgamma2, dbeta2);
   int rc = agcn_check_launch();
-  if (rc) return rc;
-  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 63) / 64), dim3(64), 0, s, (const float*)part, N, C,
-                     (double)N * (double)P, gamma1, mean1, invstd1, y2 ? gamma2 : nullptr, mean2, invstd2, coef,
-                     dgamma1, dbeta1, dgamma2, dbeta2);
-  rc = agcn_check_launch();
   if (rc) return rc;
   const unsigned t4 = (unsigned)(total / 4);
   const dim3 g(ew_grid(t4)), b(256);
@@ -314,6 +326,17 @@ int agcn_bn_bwd(const float* dout, const float* mask, const float* y1, const flo
                        (const float4*)y1, (const float4*)y2, (const float*)coef, (float4*)dy1, (float4*)dy2, t4,
                        (unsigned)P, (unsigned)C);
   return agcn_check_launch();
+}
+
+// both stages back to back (per-replica statistics).  part: (N*C*3) scratch, coef: (6*C) scratch.
+int agcn_bn_bwd(const float* dout, const float* mask, const float* y1, const float* gamma1, const float* mean1,
+                const float* invstd1, const float* y2, const float* gamma2, const float* mean2, const float* invstd2,
+                float* part, float* coef, float* dy1, float* dgamma1, float* dbeta1, float* dy2, float* dgamma2,
+                float* dbeta2, int N, int C, int P, void* stream) {
+  int rc = agcn_bn_bwd_reduce(dout, mask, y1, y2, part, N, C, P, stream);
+  if (rc) return rc;
+  return agcn_bn_bwd_apply(part, N, (double)N * (double)P, 1.0f, dout, mask, y1, gamma1, mean1, invstd1, y2, gamma2,
+                           mean2, invstd2, coef, dy1, dgamma1, dbeta1, dy2, dgamma2, dbeta2, N, C, P, stream);
 }
 
 const char* agcn_arch(void) { return "gfx950"; }

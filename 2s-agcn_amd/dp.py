@@ -30,6 +30,17 @@ def init_distributed(backend=None, device=None):
     return rank, world
 
 
+def enable_sync_bn(model, world_size, group=None):
+    """Reference DDP semantics (utils/processor.py:295 converts every BatchNorm to SyncBatchNorm): the HIP layers
+    all-reduce their per-channel sums (ops.set_sync_bn) and the stock ``data_bn`` is converted by torch.
+    Returns the (possibly converted) model.  With world_size 1 nothing changes."""
+    from . import ops
+    ops.set_sync_bn(world_size, group)
+    if world_size > 1:
+        model = torch.nn.SyncBatchNorm.convert_sync_batchnorm(model, process_group=group)
+    return model
+
+
 def allreduce_gradients(flat_grad, world_size):
     """SUM all-reduce of the flat gradient buffer (one collective per step).  The caller applies 1/world_size."""
     if world_size > 1:

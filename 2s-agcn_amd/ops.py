@@ -180,12 +180,42 @@ class BNState:
     __slots__ = ("mean", "invstd", "scale", "shift")
 
 
+# BatchNorm statistics policy of the HIP layers.  world == 1: per replica (reference nn.DataParallel semantics,
+# utils/processor.py:336-343; the default).  world > 1: synchronised over the process group like the reference's DDP
+# path (SyncBatchNorm.convert_sync_batchnorm, processor.py:295): the per-channel sums are all-reduced between the
+# two stages of the forward statistics and of the backward (one small collective each; ``dp.enable_sync_bn``).
+_SYNC_BN = {"world": 1, "group": None}
+
+
+def set_sync_bn(world, group=None):
+    _SYNC_BN["world"] = int(world)
+    _SYNC_BN["group"] = group
+
+
+def _colsum(slab, nslots, width):
+    out = _empty((width,), slab)
+    scratch = _scratch(width, slab)
+    _lib.check(_L().agcn_colsum(_lib.ptr(slab), int(nslots), int(width), scratch.data_ptr(), _lib.ptr(out),
+                                _lib.stream()), "agcn_colsum")
+    return out
+
+
+def _allreduce_sum(t):
+    import torch.distributed as dist
+    dist.all_reduce(t, op=dist.ReduceOp.SUM, group=_SYNC_BN["group"])
+    return t
+
+
 def bn_train_coeffs(stats_part, count, gamma, beta, running_mean, running_var, momentum=BN_MOMENTUM, eps=BN_EPS):
     C = gamma.numel()
     st = BNState()
     st.mean, st.invstd = _empty((C,), gamma), _empty((C,), gamma)
     st.scale, st.shift = _empty((C,), gamma), _empty((C,), gamma)
     nslots = stats_part.shape[0]
+    if _SYNC_BN["world"] > 1:      # global (sum, sumsq): reduce the slots here, all-reduce, finalize over the global count
+        stats_part = _allreduce_sum(_colsum(stats_part, nslots, 2 * C)).view(1, 2, C)
+        nslots = 1
+        count = count * _SYNC_BN["world"]
     scratch = _scratch(2 * C, gamma)
     _lib.check(_L().agcn_bn_stats_finalize(_lib.ptr(stats_part), nslots, C, float(count), _lib.ptr(gamma),
                                            _lib.ptr(beta), _lib.ptr(running_mean), _lib.ptr(running_var),
@@ -230,11 +260,23 @@ def bn_bwd(dout, mask, y1, gamma1, st1, y2=None, gamma2=None, st2=None):
     if y2 is not None:
         dy2 = torch.empty_like(y2)
         dg2, db2 = _empty((C,), y1), _empty((C,), y1)
-    _lib.check(_L().agcn_bn_bwd(
-        _lib.ptr(dout), _lib.ptr(mask), _lib.ptr(y1), _lib.ptr(gamma1), _lib.ptr(st1.mean), _lib.ptr(st1.invstd),
-        _lib.ptr(y2), _lib.ptr(gamma2), _lib.ptr(st2.mean) if st2 else None, _lib.ptr(st2.invstd) if st2 else None,
-        _lib.ptr(part), _lib.ptr(coef), _lib.ptr(dy1), _lib.ptr(dg1), _lib.ptr(db1), _lib.ptr(dy2), _lib.ptr(dg2),
-        _lib.ptr(db2), N, C, T * V, _lib.stream()), "agcn_bn_bwd")
+    world = _SYNC_BN["world"]
+    if world <= 1:
+        _lib.check(_L().agcn_bn_bwd(
+            _lib.ptr(dout), _lib.ptr(mask), _lib.ptr(y1), _lib.ptr(gamma1), _lib.ptr(st1.mean), _lib.ptr(st1.invstd),
+            _lib.ptr(y2), _lib.ptr(gamma2), _lib.ptr(st2.mean) if st2 else None, _lib.ptr(st2.invstd) if st2 else None,
+            _lib.ptr(part), _lib.ptr(coef), _lib.ptr(dy1), _lib.ptr(dg1), _lib.ptr(db1), _lib.ptr(dy2), _lib.ptr(dg2),
+            _lib.ptr(db2), N, C, T * V, _lib.stream()), "agcn_bn_bwd")
+    else:
+        _lib.check(_L().agcn_bn_bwd_reduce(_lib.ptr(dout), _lib.ptr(mask), _lib.ptr(y1), _lib.ptr(y2), _lib.ptr(part),
+                                           N, C, T * V, _lib.stream()), "agcn_bn_bwd_reduce")
+        sums = _allreduce_sum(_colsum(part, N, 3 * C))
+        _lib.check(_L().agcn_bn_bwd_apply(
+            _lib.ptr(sums), 1, float(N * T * V * world), 1.0 / world, _lib.ptr(dout), _lib.ptr(mask), _lib.ptr(y1),
+            _lib.ptr(gamma1), _lib.ptr(st1.mean), _lib.ptr(st1.invstd), _lib.ptr(y2), _lib.ptr(gamma2),
+            _lib.ptr(st2.mean) if st2 else None, _lib.ptr(st2.invstd) if st2 else None, _lib.ptr(coef), _lib.ptr(dy1),
+            _lib.ptr(dg1), _lib.ptr(db1), _lib.ptr(dy2), _lib.ptr(dg2), _lib.ptr(db2), N, C, T * V, _lib.stream()),
+            "agcn_bn_bwd_apply")
     return dy1, dg1, db1, dy2, dg2, db2
 
 

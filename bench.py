@@ -208,6 +208,8 @@ def main():
     ap.add_argument('--batch', type=int, default=0, help='per-GPU batch (default: the workload\'s, 64 for configs[1])')
     ap.add_argument('--workload', default='ntu_agcn', choices=sorted(WORKLOADS),
                     help='ntu_agcn = BASELINE configs[1]/[2] (the headline); others are the remaining configs')
+    ap.add_argument('--sync-bn', action='store_true', help='synchronised BatchNorm (reference DDP semantics); '
+                    'default per-replica statistics')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-roofline', action='store_true')
     args = ap.parse_args()
@@ -238,6 +240,9 @@ def main():
     model = build_model(args.workload)
     randomize_like_training(model, seed=0)
     model.to(device)
+    if args.sync_bn:
+        from agcn_amd import dp as _dp
+        model = _dp.enable_sync_bn(model, world)
     engine = TrainEngine(model, base_lr=0.1, momentum=0.9, nesterov=True, weight_decay=1e-4, max_grad_norm=1.0,
                          world_size=world)
     data, label = synthetic_batch(args.batch, num_point=wl[2], num_class=wl[1], seed=1234 + rank, device=device)
@@ -275,7 +280,7 @@ def main():
                                    "SGD nesterov)",
                        "per_gpu_batch": args.batch, "global_batch": args.batch * world,
                        "input": f"(N,3,300,{wl[2]},2)",
-                       "parallelism": f"dp{world}", "bn": "per-replica",
+                       "parallelism": f"dp{world}", "bn": "sync" if args.sync_bn else "per-replica",
                        "tcn_gemm": os.environ.get('AGCN_GEMM', 'bf16x6') +
                                    " (9x1 conv fwd/bwd-data; bf16x6 = fp32-equivalent split, fp32 accumulate)"},
             "final_loss": round(final_loss, 5),

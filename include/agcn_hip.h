@@ -114,6 +114,16 @@ int agcn_bn_act_fwd(const float* y1, const float* scale1, const float* shift1, c
                     const float* shift2, float* out, int N, int C, int P, int res_mode, int relu, void* stream);
 /* train-mode backward of out = relu(bn1(y1) [+ bn2(y2)] [+ identity]); mask = out (NULL: no ReLU);
  * part: scratch N*C*3 floats, coef: scratch 6*C floats */
+/* the two stages of agcn_bn_bwd, exposed so that a synchronised BatchNorm (reference utils/processor.py:295) can
+ * all-reduce the per-channel sums between them: part is (N*C*3); apply sums `nrows` rows of it per channel, uses
+ * `count` elements per channel and scales dgamma/dbeta by param_grad_scale. */
+int agcn_bn_bwd_reduce(const float* dout, const float* mask, const float* y1, const float* y2, float* part, int N, int C,
+                       int P, void* stream);
+int agcn_bn_bwd_apply(const float* part, int nrows, double count, float param_grad_scale, const float* dout,
+                      const float* mask, const float* y1, const float* gamma1, const float* mean1, const float* invstd1,
+                      const float* y2, const float* gamma2, const float* mean2, const float* invstd2, float* coef,
+                      float* dy1, float* dgamma1, float* dbeta1, float* dy2, float* dgamma2, float* dbeta2, int N, int C,
+                      int P, void* stream);
 int agcn_bn_bwd(const float* dout, const float* mask, const float* y1, const float* gamma1, const float* mean1,
                 const float* invstd1, const float* y2, const float* gamma2, const float* mean2, const float* invstd2,
                 float* part, float* coef, float* dy1, float* dgamma1, float* dbeta1, float* dy2, float* dgamma2,
