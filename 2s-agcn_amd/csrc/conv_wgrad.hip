@@ -257,6 +257,48 @@ __global__ void wgrad_reduce_kernel(const float* __restrict__ part, float* __res
   dw[(long)m * so_m + (long)z * so_t + (long)c * so_c] = s;
 }
 
+// Same sum for many slabs of a small gradient (split-K over up to 1024 workgroup shares): 32 elements x 8 slab
+// groups per block; a thread adds every 8th slab (unrolled: 8 loads in flight), the 8 partial sums are combined in
+// a fixed order, so the result is still bitwise reproducible.
+__global__ void __launch_bounds__(256)
+wgrad_reduce_wide_kernel(const float* __restrict__ part, float* __restrict__ dw, long wsize, int nsplit, int M, int C,
+                         long so_m, long so_t, long so_c) {
+  __shared__ float red[8][32];
+  const int el = threadIdx.x & 31, g = threadIdx.x >> 5;
+  const long i = (long)blockIdx.x * 32 + el;
+  float s = 0.f;
+  if (i < wsize) {
+#pragma unroll 8
+    for (int k = g; k < nsplit; k += 8) s += part[(long)k * wsize + i];
+  }
+  red[g][el] = s;
+  __syncthreads();
+  if (g == 0 && i < wsize) {
+    float t = red[0][el];
+#pragma unroll
+    for (int k = 1; k < 8; ++k) t += red[k][el];
+    const int c = (int)(i % C);
+    const long r = i / C;
+    const int m = (int)(r % M);
+    const int z = (int)(r / M);
+    dw[(long)m * so_m + (long)z * so_t + (long)c * so_c] = t;
+  }
+}
+
+// picks the reduction shape by slab count
+inline int launch_reduce(const float* ws, float* dw, long wsize, int nslabs, int M, int C, long so_m, long so_t, long so_c,
+                         hipStream_t stream) {
+  if (nslabs >= 64) {
+    hipLaunchKernelGGL(wgrad_reduce_wide_kernel, dim3((unsigned)((wsize + 31) / 32)), dim3(256), 0, stream, ws, dw,
+                       wsize, nslabs, M, C, so_m, so_t, so_c);
+  } else {
+    const int threads = 256;
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((wsize + threads - 1) / threads)), dim3(threads), 0,
+                       stream, ws, dw, wsize, nslabs, M, C, so_m, so_t, so_c);
+  }
+  return agcn_check_launch();
+}
+
 struct WGeom {
   int tt, ntiles, FW, WLP, DAP, GP, nsplit, nslabs, pairs_per_split, grid_x;
   int off_bx, off_bg, off_adj, off_qoff;
@@ -320,10 +362,7 @@ int launch_wgrad(WgradArgs a, float* dw, void* ws, size_t ws_bytes, hipStream_t 
   hipLaunchKernelGGL(kern, dim3(g.grid_x, g.nsplit), dim3(512), g.smem_bytes, stream, a);
   int rc = agcn_check_launch();
   if (rc) return rc;
-  const int threads = 256;
-  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((a.wsize + threads - 1) / threads)), dim3(threads), 0,
-                     stream, (const float*)ws, dw, a.wsize, g.nslabs, a.M, a.C, a.so_m, a.so_t, a.so_c);
-  return agcn_check_launch();
+  return launch_reduce((const float*)ws, dw, a.wsize, g.nslabs, a.M, a.C, a.so_m, a.so_t, a.so_c, stream);
 }
 
 template <int TAPS, int AGG, int MW, int CW, int TH, bool KSPLIT>
@@ -338,10 +377,7 @@ int chain_wgrad_and_reduce(int agg, const WgradArgs& a, float* dw, void* ws, siz
   int rc = agcn_wgrad_chain(agg, a.dy, a.in, a.adj, ws, ws_bytes, &nslabs, a.N, a.M, a.C, a.V, a.T_src, a.T_out,
                             a.stride, stream);
   if (rc) return rc;
-  const int threads = 256;
-  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((a.wsize + threads - 1) / threads)), dim3(threads), 0,
-                     stream, (const float*)ws, dw, a.wsize, nslabs, a.M, a.C, a.so_m, a.so_t, a.so_c);
-  return agcn_check_launch();
+  return launch_reduce((const float*)ws, dw, a.wsize, nslabs, a.M, a.C, a.so_m, a.so_t, a.so_c, stream);
 }
 
 inline bool chain_wgrad_enabled() {
