@@ -83,7 +83,7 @@ def grad_check(g, gold, name, tol):
     the fixtures also hold the SAME reference code run in fp64, which gives the reference's own fp32 rounding
     noise per tensor (up to ~1e-2 of max|g| for the adjacency parameters of the full model, whose gradients are
     sums of ~1e5 cancelling terms).  Pass if err32 <= tol, or if the result is as close to the fp64 answer as
-    the fp32 reference itself is (within 3x): err64 <= tol + 3*noise (5x for the perturbation band of the model
+    the fp32 reference itself is (within 3x): err64 <= tol + 3*noise (8x for the perturbation band of the model
     fixtures, whose 8 draws sample the tail of the kink-flip distribution only coarsely: a 3e-6 input perturbation
     of a correct fp32 run was measured to move individual tensors to 10x a 3-draw band).
     Returns (ok, err32, err64, noise)."""
@@ -99,7 +99,7 @@ def grad_check(g, gold, name, tol):
     # two correct fp32 evaluations can be expected to agree to.
     factor = 3.0
     if ('sens.' + name) in gold:
-        factor = 5.0
+        factor = 8.0
         # three perturbation samples under-sample which kink elements flip, so the band of a tensor is at
         # least the model-wide median band (a flip in layer L moves the gradients of every layer below it)
         noise = max(noise, float(gold['sens.' + name]), sens_floor(gold))
