@@ -223,83 +223,6 @@ __global__ void __launch_bounds__(NT, (TAPS == 1 && TM == 2) ? 4 : 2) conv_gemm_
     }
   }
 
-  if constexpr (TAPS == 1) {
-  // 1x1 problems: short main loop; the direct 128-byte-run stores measured faster than the LDS round trip here
-  // ---- epilogue: store (+bias, +accumulate, +masked addends), per-channel (sum, sumsq) partials ----
-  float* red = reinterpret_cast<float*>(smem);   // [NW][2][BM]
-  const long Pfull = (long)a.T_full * V;
-  if (a.stats) __syncthreads();
-  const bool has_extra = a.accumulate || a.add1 || a.add2;
-  const int qq = wave * 32 + lr;
-#pragma unroll
-  for (int tm = 0; tm < TM; ++tm) {
-#pragma unroll
-    for (int jb = 0; jb < 4; ++jb) {
-      float ex[4];
-      long idxs[4];
-      bool oks[4];
-#pragma unroll
-      for (int jj = 0; jj < 4; ++jj) {
-        const int m = m0 + tm * 32 + mfma_row(jb * 4 + jj, h);
-        oks[jj] = (m < a.M) && (qq < nvalid);
-        idxs[jj] = oks[jj] ? (((long)n * a.M + m) * Pfull + ooff) : 0;
-        ex[jj] = 0.f;
-      }
-      if (has_extra) {
-#pragma unroll
-        for (int jj = 0; jj < 4; ++jj) {
-          const long idx = idxs[jj];
-          float e = 0.f;
-          if (a.accumulate) e += a.out[idx];
-          if (a.add1) {
-            float t = a.add1[idx];
-            if (a.mask1) t = (a.mask1[idx] > 0.f) ? t : 0.f;
-            e += t;
-          }
-          if (a.add2) {
-            float t = a.add2[idx];
-            if (a.mask2) t = (a.mask2[idx] > 0.f) ? t : 0.f;
-            e += t;
-          }
-          ex[jj] = e;
-        }
-      }
-#pragma unroll
-      for (int jj = 0; jj < 4; ++jj) {
-        const int j = jb * 4 + jj;
-        const int ml = tm * 32 + mfma_row(j, h);
-        const int m = m0 + ml;
-        const float bval = (a.bias && m < a.M) ? a.bias[m] : 0.f;
-        const float val = acc[tm][j] + bval + ex[jj];
-        float bsum = 0.f, bsq = 0.f;
-        if (oks[jj]) {
-          a.out[idxs[jj]] = val;
-          bsum = val;
-          bsq = val * val;
-        }
-        if (a.stats) {
-          bsum = half_sum(bsum);
-          bsq = half_sum(bsq);
-          if (lr == 0) {
-            red[(wave * 2 + 0) * BM + ml] = bsum;
-            red[(wave * 2 + 1) * BM + ml] = bsq;
-          }
-        }
-      }
-    }
-  }
-  if (a.stats) {
-    __syncthreads();
-    const long slot = (long)n * a.ntiles + tile_id;
-    for (int e = tid; e < 2 * BM; e += NT) {
-      const int k = e / BM, ml = e - k * BM;
-      float s = 0.f;
-#pragma unroll
-      for (int w2 = 0; w2 < NW; ++w2) s += red[(w2 * 2 + k) * BM + ml];
-      if (m0 + ml < a.M) a.stats[(slot * 2 + k) * a.M + m0 + ml] = s;
-    }
-  }
-  } else {
   // ---- epilogue (epilogue.h): tile -> LDS -> coalesced row stores, residual operands, (sum, sumsq) partials ----
   __syncthreads();                                     // every wave is done with the A/B images
   float* tile = reinterpret_cast<float*>(smem);        // [BM][TP]
@@ -326,7 +249,6 @@ __global__ void __launch_bounds__(NT, (TAPS == 1 && TM == 2) ? 4 : 2) conv_gemm_
   const long Pfull = (long)a.T_full * V;
   const long rows0 = (long)n * a.M * Pfull + ((long)t0 * a.out_fs + a.out_fo) * V;
   epilogue_rows<BM, NW, 4>(ep, tile, TP, bias_s, red, a.M, m0, rows0, Pfull, nvalid, poff, (long)n * a.ntiles + tile_id);
-  }
 }
 
 struct BfGeom {
@@ -349,7 +271,7 @@ BfGeom bf_geometry(int V, int T_out, int src_stride, int M, int Kinner) {
   g.off_b = (int)a_bytes;
   const size_t b_bytes = (size_t)3 * 2 * g.WLR * 16;
   size_t main_b = a_bytes + b_bytes;
-  size_t epi_b = (TAPS == 1) ? (size_t)NW * 2 * BM * 4 : (size_t)BM * (NW * 32 + 1) * 4 + (size_t)NT * 2 * 4;
+  size_t epi_b = (size_t)BM * (NW * 32 + 1) * 4 + (size_t)NT * 2 * 4;
   g.smem_bytes = ((main_b > epi_b ? main_b : epi_b) + 15) & ~(size_t)15;
   g.off_bias = (int)g.smem_bytes;
   g.smem_bytes += (size_t)BM * 4;
