@@ -41,6 +41,28 @@ class FlatParams:
             p.grad = self.grad[o:o + n].view(p.shape)
         self.offsets = offs
 
+    def views(self):
+        return [self.grad[o:o + p.numel()].view(p.shape) for p, o in zip(self.params, self.offsets)]
+
+    def detach_grads(self):
+        """Let autograd ASSIGN the gradients (p.grad = None beforehand) instead of accumulating into the flat views:
+        an accumulation is one tiny add kernel per parameter tensor (274 launches, 1.2 ms per step)."""
+        for p in self.params:
+            p.grad = None
+
+    def gather_grads(self):
+        """Bring the gradients autograd produced into the flat buffer with one multi-tensor copy and re-attach the
+        views (parameters that received no gradient count as zero, like zero_grad + accumulate would give)."""
+        views = self.views()
+        got = [(v, p.grad) for v, p in zip(views, self.params) if p.grad is not None]
+        missing = [v for v, p in zip(views, self.params) if p.grad is None]
+        if missing:
+            torch._foreach_zero_(missing)
+        if got:
+            torch._foreach_copy_([v for v, _ in got], [g for _, g in got])
+        for p, v in zip(self.params, views):
+            p.grad = v
+
     def zero_grad(self):
         self.grad.zero_()
         for p, o in zip(self.params, self.offsets):      # re-attach if something replaced .grad
@@ -80,8 +102,9 @@ class TrainEngine:
         if isinstance(output, tuple):
             output = output[0]
         loss = self.loss_fn(output, label)
-        self.fp.zero_grad()
+        self.fp.detach_grads()
         loss.backward()
+        self.fp.gather_grads()
         _dp.allreduce_gradients(self.fp.grad, self.world_size)     # RCCL over xGMI; averaged inside the update
         if before_step is not None:
             before_step()
