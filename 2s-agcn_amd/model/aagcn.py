@@ -302,6 +302,12 @@ class BaseModel(nn.Module):
         return self.fc(self.drop_out(x))
 
     def forward(self, x):
+        import torch.distributed as dist
+        bn = self.l1.gcn1.bn
+        if isinstance(bn, nn.SyncBatchNorm) and dist.is_available() and dist.is_initialized():
+            ops.set_sync_bn(dist.get_world_size(bn.process_group), bn.process_group)   # see agcn.follow_sync_batchnorm
+        else:
+            ops.set_sync_bn(1)
         size = x.size()
         x = self.forward_preprocess(x, size)
         x = self.forward_model_backbone(x, size)

@@ -56,6 +56,20 @@ def _bn_args(bn):
     return bn.weight, bn.bias, bn.running_mean, bn.running_var
 
 
+def follow_sync_batchnorm(model):
+    """The reference's DDP path converts every BatchNorm with ``SyncBatchNorm.convert_sync_batchnorm`` before wrapping
+    the model (utils/processor.py:295).  The HIP units only borrow the BN modules' parameters, so the conversion is
+    honoured here: if the unit BNs have become SyncBatchNorm and a process group is up, the HIP BatchNorm stages
+    all-reduce their sums (ops.set_sync_bn).  Called once per forward of the top-level model; cheap."""
+    import torch.distributed as dist
+    bn = model.l1.gcn1.bn
+    if isinstance(bn, nn.SyncBatchNorm) and dist.is_available() and dist.is_initialized():
+        group = bn.process_group
+        ops.set_sync_bn(dist.get_world_size(group), group)
+    else:
+        ops.set_sync_bn(1)
+
+
 def _bn_tick(bn, training):
     if training and bn.num_batches_tracked is not None:
         bn.num_batches_tracked.add_(1)
@@ -207,6 +221,7 @@ class Model(nn.Module):
         bn_init(self.data_bn, 1)
 
     def forward(self, x):
+        follow_sync_batchnorm(self)
         N, C, T, V, M = x.size()
         x = x.permute(0, 4, 3, 1, 2).contiguous().view(N, M * V * C, T)
         x = self.data_bn(x)

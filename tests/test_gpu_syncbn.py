@@ -43,7 +43,8 @@ def worker():
     torch.nn.functional.cross_entropy(out_ref, y).backward()
     gref = torch.cat([p.grad.flatten() for p in ref.parameters()])
     # this rank's half with synchronised statistics
-    m = dp.enable_sync_bn(build(), world)
+    # the reference way: convert the BatchNorms; the HIP stages follow (model/agcn.py::follow_sync_batchnorm)
+    m = torch.nn.SyncBatchNorm.convert_sync_batchnorm(build())
     xs, ys = x[rank::world], y[rank::world]
     out = m(xs)
     torch.nn.functional.cross_entropy(out, ys).backward()
