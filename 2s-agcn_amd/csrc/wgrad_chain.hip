@@ -53,7 +53,7 @@ template <int AGG, int TM, int NCB, int VS>
 __global__ void __launch_bounds__(512, 2) wgrad_chain_kernel(const WcArgs a) {
   constexpr int NW = 8, NT = 512, BM = TM * 32;
   constexpr int NFG = NW / NCB;                 // frame groups
-  constexpr int FPW = (NCB == 2) ? 1 : 2;       // frames per wave per stage
+  constexpr int FPW = (NCB <= 2) ? 1 : 2;       // frames per wave per stage
   constexpr int FT = NFG * FPW;                 // frames per stage
   constexpr int CG = NCB * 32;                  // channels per workgroup
   constexpr int DI = BM * FT * 4 / NT;          // dy staging items (o, f, ks, h) per thread
@@ -249,7 +249,7 @@ struct WcGeom {
 
 template <int AGG, int TM, int NCB>
 WcGeom wc_geom(int N, int M, int C, int V, int T_out) {
-  constexpr int BM = TM * 32, NFG = 8 / NCB, FPW = (NCB == 2) ? 1 : 2, FT = NFG * FPW, CG = NCB * 32;
+  constexpr int BM = TM * 32, NFG = 8 / NCB, FPW = (NCB <= 2) ? 1 : 2, FT = NFG * FPW, CG = NCB * 32;
   WcGeom g;
   g.ntiles = (T_out + FT - 1) / FT;
   g.ncg = (C + CG - 1) / CG;
@@ -300,22 +300,25 @@ template <int AGG, int TM>
 int wc_dispatch_ncb(const WcArgs& a, void* ws, size_t ws_bytes, int* nslabs, hipStream_t s) {
   if (a.C % 256 == 0) return wc_dispatch_vs<AGG, TM, 8>(a, ws, ws_bytes, nslabs, s);
   if (a.C % 128 == 0) return wc_dispatch_vs<AGG, TM, 4>(a, ws, ws_bytes, nslabs, s);
-  return wc_dispatch_vs<AGG, TM, 2>(a, ws, ws_bytes, nslabs, s);
+  if (a.C % 64 == 0) return wc_dispatch_vs<AGG, TM, 2>(a, ws, ws_bytes, nslabs, s);
+  return wc_dispatch_vs<AGG, TM, 1>(a, ws, ws_bytes, nslabs, s);     // few channels (first layer): one zero-padded block
 }
 
 template <int AGG>
 size_t wc_slabs(int N, int M, int C, int V, int T_out) {
-  const bool tm4 = M > 64;
+  const bool tm4 = M > 64 && C % 64 == 0;     // the single-block (few channels) variant stages 8 frames: 64 rows only
   int n;
   if (C % 256 == 0) n = tm4 ? wc_geom<AGG, 4, 8>(N, M, C, V, T_out).nslabs : wc_geom<AGG, 2, 8>(N, M, C, V, T_out).nslabs;
   else if (C % 128 == 0) n = tm4 ? wc_geom<AGG, 4, 4>(N, M, C, V, T_out).nslabs : wc_geom<AGG, 2, 4>(N, M, C, V, T_out).nslabs;
-  else n = tm4 ? wc_geom<AGG, 4, 2>(N, M, C, V, T_out).nslabs : wc_geom<AGG, 2, 2>(N, M, C, V, T_out).nslabs;
+  else if (C % 64 == 0) n = tm4 ? wc_geom<AGG, 4, 2>(N, M, C, V, T_out).nslabs : wc_geom<AGG, 2, 2>(N, M, C, V, T_out).nslabs;
+  else n = tm4 ? wc_geom<AGG, 4, 1>(N, M, C, V, T_out).nslabs : wc_geom<AGG, 2, 1>(N, M, C, V, T_out).nslabs;
   return (size_t)n;
 }
 
 }  // namespace
 
-bool agcn_wgrad_chain_supported(int M, int C, int V) { return M >= 64 && C >= 64 && C % 64 == 0 && V <= 32; }
+// C a multiple of 64, or at most 32 (one zero-padded channel block)
+bool agcn_wgrad_chain_supported(int M, int C, int V) { return M >= 64 && (C % 64 == 0 || C <= 32) && C >= 1 && V <= 32; }
 
 size_t agcn_wgrad_chain_workspace(int agg, int N, int M, int C, int V, int T_out) {
   const long wsize = (long)(agg ? 3 : 1) * M * C;
@@ -328,6 +331,7 @@ int agcn_wgrad_chain(int agg, const float* dy, const float* x, const float* adj,
   WcArgs a = {};
   a.dy = dy; a.in = x; a.adj = adj; a.N = N; a.M = M; a.C = C; a.V = V; a.T_src = T_src; a.T_out = T_out;
   a.stride = stride; a.wsize = (long)(agg ? 3 : 1) * M * C;
-  if (agg) return (M > 64) ? wc_dispatch_ncb<1, 4>(a, ws, ws_bytes, nslabs, s) : wc_dispatch_ncb<1, 2>(a, ws, ws_bytes, nslabs, s);
-  return (M > 64) ? wc_dispatch_ncb<0, 4>(a, ws, ws_bytes, nslabs, s) : wc_dispatch_ncb<0, 2>(a, ws, ws_bytes, nslabs, s);
+  const bool tm4 = M > 64 && C % 64 == 0;
+  if (agg) return tm4 ? wc_dispatch_ncb<1, 4>(a, ws, ws_bytes, nslabs, s) : wc_dispatch_ncb<1, 2>(a, ws, ws_bytes, nslabs, s);
+  return tm4 ? wc_dispatch_ncb<0, 4>(a, ws, ws_bytes, nslabs, s) : wc_dispatch_ncb<0, 2>(a, ws, ws_bytes, nslabs, s);
 }
