@@ -648,8 +648,8 @@ int dadj_chain_launch(DadjArgs a, const float* wcat, void* ws, size_t ws_bytes, 
 
 }  // namespace
 
-// rows per block: 128 when M is a multiple of 128, else 64
-static inline int chain_tm(int M) { return (M % 128 == 0) ? 4 : 2; }
+// rows per block: 128 when M is a multiple of 128, 32 for the few-channel first layer, else 64
+static inline int chain_tm(int M) { return (M % 128 == 0) ? 4 : (M <= 32 ? 1 : 2); }
 
 // waves (= frames) per workgroup: 4 (two workgroups per CU overlap each other's prologue/epilogue) or 8
 static inline int chain_waves() {
@@ -661,12 +661,14 @@ static inline int chain_waves() {
   return nw;
 }
 
-bool agcn_gcn_chain_supported(int M, int K, int V) { return M >= 64 && K >= CB && V <= 32; }
+bool agcn_gcn_chain_supported(int M, int K, int V) { return M >= 1 && K >= 1 && V <= 32; }
 
 int agcn_gcn_chain_tiles(int T) { return (T + chain_waves() - 1) / chain_waves(); }
 
 size_t agcn_gcn_chain_workspace(int M, int K, int T, int V) {   // pack size does not depend on the frame tile
-  return chain_tm(M) == 4 ? chain_geometry<4, 8>(V, T, M, K).pack_bytes : chain_geometry<2, 8>(V, T, M, K).pack_bytes;
+  const int tm = chain_tm(M);
+  return tm == 4 ? chain_geometry<4, 8>(V, T, M, K).pack_bytes
+                 : (tm == 2 ? chain_geometry<2, 8>(V, T, M, K).pack_bytes : chain_geometry<1, 8>(V, T, M, K).pack_bytes);
 }
 
 // mode 0: forward (in = x, K = C, M = Cout); mode 1: backward-data (in = dy, K = Cout, M = C)
@@ -681,11 +683,12 @@ int agcn_gcn_chain(int mode, const float* in, const float* adj, const float* wca
   long sa_m, sa_i, sa_c;
   if (mode == 0) { a.M = Cout; a.K = C; a.adj_t = 0; sa_m = 3L * C; sa_i = C; sa_c = 1; }
   else           { a.M = C; a.K = Cout; a.adj_t = 1; sa_m = 1; sa_i = C; sa_c = 3L * C; }
-  if (chain_waves() == 8) {
+  if (chain_waves() == 8 && chain_tm(a.M) != 1) {
     if (chain_tm(a.M) == 4) return chain_dispatch_vs<4, 8>(a, wcat, sa_m, sa_i, sa_c, ws, ws_bytes, stream);
     return chain_dispatch_vs<2, 8>(a, wcat, sa_m, sa_i, sa_c, ws, ws_bytes, stream);
   }
   if (chain_tm(a.M) == 4) return chain_dispatch_vs<4, 4>(a, wcat, sa_m, sa_i, sa_c, ws, ws_bytes, stream);
+  if (chain_tm(a.M) == 1) return chain_dispatch_vs<1, 4>(a, wcat, sa_m, sa_i, sa_c, ws, ws_bytes, stream);
   return chain_dispatch_vs<2, 4>(a, wcat, sa_m, sa_i, sa_c, ws, ws_bytes, stream);
 }
 
