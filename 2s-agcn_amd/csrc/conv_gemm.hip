@@ -93,7 +93,7 @@ __device__ __forceinline__ f32x16 agg_chain(const float* bxrow, const float* adj
 
 // WB = max number of 64-float column blocks of a staged window row (compile-time bound of the prefetch registers)
 template <int TAPS, int AGG, int WM, int WN, int TM, int TN, int CK, int WB, int EPI>
-__global__ void __launch_bounds__(WM* WN * 64, (WM * WN == 8 && TAPS == 1) ? 4 : 2) conv_gemm_kernel(const ConvGemmArgs a) {
+__global__ void __launch_bounds__(WM* WN * 64, (TAPS == 1 && EPI == 0) ? 4 : 2) conv_gemm_kernel(const ConvGemmArgs a) {
   constexpr int NW = WM * WN, NT = NW * 64;
   constexpr int BM = WM * TM * 32;
   constexpr int NSUB = AGG ? 3 : 1;
@@ -543,7 +543,7 @@ size_t pack_bytes(int V, int T_out, int src_stride, int M, int Kinner) {
   (((M) % 128 == 0) ? pack_bytes<TAPS, AGG, 2, 4, 2, 2, CK128, 0>(V, T, ss, M, K)            \
                     : pack_bytes<TAPS, AGG, 1, 4, 2, 2, CK64, 0>(V, T, ss, M, K))
 
-constexpr int CK9 = 8, CK1 = 32, CKA = 8, CKD = 64;
+constexpr int CK9 = 8, CK1 = 16, CKA = 8, CKD = 64;
 
 
 }  // namespace
