@@ -38,22 +38,32 @@ scores_fwd_kernel(const float* __restrict__ tp, float* __restrict__ spart, int N
   const int lc = min(lr, V - 1);
   for (int c0 = 0; c0 < Ci; c0 += SC_CK) {
     __syncthreads();
-    for (int q = lane; q < ttv; q += 64) {          // 4 rows x 2 tensors in flight per lane
-      float v1[SC_CK / 4], v2[SC_CK / 4];
+    {   // whole chunk fetched before any LDS write: 32 loads in flight per lane (latency-bound kernel)
+      float v1[4][SC_CK / 4], v2[4][SC_CK / 4];
 #pragma unroll
-      for (int j = 0; j < SC_CK / 4; ++j) {
-        const int cl = wave + 4 * j;
-        const bool ok = (c0 + cl) < Ci && q < nvalid;
-        const long o = (long)(c0 + ((c0 + cl) < Ci ? cl : 0)) * P + (ok ? q : 0);
-        const float t1 = th_base[o], t2 = ph_base[o];
-        v1[j] = ok ? t1 : 0.f;
-        v2[j] = ok ? t2 : 0.f;
+      for (int u = 0; u < 4; ++u) {
+        const int q = lane + 64 * u;
+#pragma unroll
+        for (int j = 0; j < SC_CK / 4; ++j) {
+          const int cl = wave + 4 * j;
+          const bool ok = (c0 + cl) < Ci && q < nvalid;
+          const long o = (long)(c0 + ((c0 + cl) < Ci ? cl : 0)) * P + (ok ? q : 0);
+          v1[u][j] = th_base[o];
+          v2[u][j] = ph_base[o];
+        }
       }
 #pragma unroll
-      for (int j = 0; j < SC_CK / 4; ++j) {
-        const int cl = wave + 4 * j;
-        Th[cl * ttv + q] = v1[j];
-        Ph[cl * ttv + q] = v2[j];
+      for (int u = 0; u < 4; ++u) {
+        const int q = lane + 64 * u;
+#pragma unroll
+        for (int j = 0; j < SC_CK / 4; ++j) {
+          const int cl = wave + 4 * j;
+          const bool ok = (c0 + cl) < Ci && q < nvalid;
+          if (q < ttv) {
+            Th[cl * ttv + q] = ok ? v1[u][j] : 0.f;
+            Ph[cl * ttv + q] = ok ? v2[u][j] : 0.f;
+          }
+        }
       }
     }
     __syncthreads();
@@ -199,23 +209,35 @@ scores_bwd_kernel(const float* __restrict__ tp, const float* __restrict__ dS, fl
   const int nrt = (nrows + 31) >> 5;
   for (int c0 = 0; c0 < Ci; c0 += SC_CK) {
     __syncthreads();
-    for (int q = lane; q < ttv; q += 64) {          // 4 rows x 2 tensors in flight per lane
-      float v1[SC_CK / 4], v2[SC_CK / 4];
+    // the whole chunk (4 rows x 2 tensors x up to 4 column blocks per lane) is fetched before anything is written
+    // to LDS: 32 loads in flight per lane instead of 8 (the kernel is latency-bound, not bandwidth-bound)
+    {
+      float v1[4][SC_CK / 4], v2[4][SC_CK / 4];
 #pragma unroll
-      for (int j = 0; j < SC_CK / 4; ++j) {
-        const int cl = wave + 4 * j;
-        const bool okr = (c0 + cl) < Ci;
-        const bool ok = okr && q < nvalid;
-        const float* s1 = tp + (row0 + c0 + (okr ? cl : 0)) * P + (long)t0 * V;
-        const float t1 = s1[ok ? q : 0], t2 = s1[(long)Ci * P + (ok ? q : 0)];
-        v1[j] = ok ? t1 : 0.f;
-        v2[j] = ok ? t2 : 0.f;
+      for (int u = 0; u < 4; ++u) {
+        const int q = lane + 64 * u;
+#pragma unroll
+        for (int j = 0; j < SC_CK / 4; ++j) {
+          const int cl = wave + 4 * j;
+          const bool okr = (c0 + cl) < Ci;
+          const bool ok = okr && q < nvalid;
+          const float* s1 = tp + (row0 + c0 + (okr ? cl : 0)) * P + (long)t0 * V;
+          v1[u][j] = s1[ok ? q : 0];
+          v2[u][j] = s1[(long)Ci * P + (ok ? q : 0)];
+        }
       }
 #pragma unroll
-      for (int j = 0; j < SC_CK / 4; ++j) {
-        const int cl = wave + 4 * j;
-        Th[cl * ttv + q] = v1[j];
-        Ph[cl * ttv + q] = v2[j];
+      for (int u = 0; u < 4; ++u) {
+        const int q = lane + 64 * u;
+#pragma unroll
+        for (int j = 0; j < SC_CK / 4; ++j) {
+          const int cl = wave + 4 * j;
+          const bool ok = (c0 + cl) < Ci && q < nvalid;
+          if (q < ttv) {
+            Th[cl * ttv + q] = ok ? v1[u][j] : 0.f;
+            Ph[cl * ttv + q] = ok ? v2[u][j] : 0.f;
+          }
+        }
       }
     }
     __syncthreads();
