@@ -177,7 +177,7 @@ __global__ void dpa_reduce_kernel(const float* __restrict__ dadj, float* __restr
 
 // dtheta_i[c',t,u] = sum_v dS_i[u,v] phi_i[c',t,v];  dphi_i[c',t,v] = sum_u dS_i[u,v] theta_i[c',t,u]
 // (dS already carries the 1/K).  Also per-row sums for the conv_a/conv_b bias gradients.
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(256, 3)
 scores_bwd_kernel(const float* __restrict__ tp, const float* __restrict__ dS, float* __restrict__ dtp,
                   float* __restrict__ dbpart, int N, int Ci, int T, int V, int tt, int ntiles) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -242,30 +242,96 @@ scores_bwd_kernel(const float* __restrict__ tp, const float* __restrict__ dS, fl
     }
     __syncthreads();
     // tiles 0..nrt-1: dtheta from phi rows ; nrt..2nrt-1: dphi from theta rows
-    for (int tl = wave; tl < 2 * nrt; tl += 4) {
-      const int which = tl / nrt, rt = tl - which * nrt;
-      const float* src = which == 0 ? Ph : Th;
-      const float* Bf = which == 0 ? B1 : B2;
-      const int row = min(rt * 32 + lr, nrows - 1);
-      f32x16 d;
+    if (2 * nrt <= 12) {
+      // Coalesced variant (at most 12 tiles, e.g. V = 25): every wave keeps its (up to 3) result tiles in registers, the results then
+      // overwrite the operand tiles in place (tile row r2, column v = LDS element r2*V + v of the [channel][position]
+      // image) and leave as whole 1000-byte rows; the bias-gradient row sums are one wave reduction per channel.
+      f32x16 dd[3];
 #pragma unroll
-      for (int j = 0; j < 16; ++j) d[j] = 0.f;
-      for (int s = 0; s < VS; ++s) {
-        const int k = 2 * s + h;
-        float av = src[row * V + min(k, V - 1)];
-        av = (k < V) ? av : 0.f;
-        d = mfma32(av, Bf[k * 32 + lr], d);
+      for (int k = 0; k < 3; ++k) {
+        const int tl = wave + 4 * k;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) dd[k][j] = 0.f;
+        if (tl < 2 * nrt) {
+          const int which = tl / nrt, rt = tl - which * nrt;
+          const float* src = which == 0 ? Ph : Th;
+          const float* Bf = which == 0 ? B1 : B2;
+          const int row = min(rt * 32 + lr, nrows - 1);
+          for (int s2 = 0; s2 < VS; ++s2) {
+            const int k2 = 2 * s2 + h;
+            float av = src[row * V + min(k2, V - 1)];
+            av = (k2 < V) ? av : 0.f;
+            dd[k] = mfma32(av, Bf[k2 * 32 + lr], dd[k]);
+          }
+        }
       }
+      __syncthreads();                       // every wave is done reading the operand tiles
 #pragma unroll
-      for (int j = 0; j < 16; ++j) {
-        const int r2 = rt * 32 + mfma_row(j, h);
-        const int cl = r2 / tt, t_l = r2 - cl * tt;
-        const bool ok = r2 < nrows && (c0 + cl) < Ci && t_l < tvalid;
-        const float val = (ok && lr < V) ? d[j] : 0.f;
-        if (ok && lr < V)
-          dtp[(row0 + (long)which * Ci + c0 + cl) * P + (long)(t0 + t_l) * V + lr] = val;
-        const float rs = half_sum(val);
-        if (lr == 0 && r2 < nrows) rows[which * nrows + r2] = rs;
+      for (int k = 0; k < 3; ++k) {
+        const int tl = wave + 4 * k;
+        if (tl < 2 * nrt) {
+          const int which = tl / nrt, rt = tl - which * nrt;
+          float* dstb = which == 0 ? Th : Ph;
+#pragma unroll
+          for (int j = 0; j < 16; ++j) {
+            const int r2 = rt * 32 + mfma_row(j, h);
+            if (r2 < nrows && lr < V) dstb[r2 * V + lr] = dd[k][j];
+          }
+        }
+      }
+      __syncthreads();
+#pragma unroll
+      for (int which = 0; which < 2; ++which) {
+        const float* buf = which == 0 ? Th : Ph;
+#pragma unroll
+        for (int j = 0; j < SC_CK / 4; ++j) {
+          const int cl = wave + 4 * j;
+          const bool okr = (c0 + cl) < Ci;
+          float* drow = dtp + (row0 + (long)which * Ci + c0 + (okr ? cl : 0)) * P + (long)t0 * V;
+          float sum = 0.f;
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            const int q = lane + 64 * u;
+            if (okr && q < nvalid) {
+              const float val = buf[cl * ttv + q];
+              drow[q] = val;
+              sum += val;
+            }
+          }
+          sum = half_sum(sum);
+          sum += __shfl_xor(sum, 32);
+          if (lane == 0) rows[which * nrows + cl * tt] = sum;       // slot of (channel cl, frame 0); others zeroed below
+        }
+      }
+      // the row-sum table is indexed per (channel, frame): frames 1.. hold nothing in this variant
+      for (int e = tid; e < 2 * nrows; e += 256)
+        if ((e % nrows) % tt != 0) rows[e] = 0.f;
+    } else {
+    for (int tl = wave; tl < 2 * nrt; tl += 4) {
+        const int which = tl / nrt, rt = tl - which * nrt;
+        const float* src = which == 0 ? Ph : Th;
+        const float* Bf = which == 0 ? B1 : B2;
+        const int row = min(rt * 32 + lr, nrows - 1);
+        f32x16 d;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) d[j] = 0.f;
+        for (int s = 0; s < VS; ++s) {
+          const int k = 2 * s + h;
+          float av = src[row * V + min(k, V - 1)];
+          av = (k < V) ? av : 0.f;
+          d = mfma32(av, Bf[k * 32 + lr], d);
+        }
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+          const int r2 = rt * 32 + mfma_row(j, h);
+          const int cl = r2 / tt, t_l = r2 - cl * tt;
+          const bool ok = r2 < nrows && (c0 + cl) < Ci && t_l < tvalid;
+          const float val = (ok && lr < V) ? d[j] : 0.f;
+          if (ok && lr < V)
+            dtp[(row0 + (long)which * Ci + c0 + cl) * P + (long)(t0 + t_l) * V + lr] = val;
+          const float rs = half_sum(val);
+          if (lr == 0 && r2 < nrows) rows[which * nrows + r2] = rs;
+        }
       }
     }
     __syncthreads();
