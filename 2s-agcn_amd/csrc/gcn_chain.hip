@@ -545,9 +545,21 @@ __global__ void __launch_bounds__(NW * 64, 2) gcn_dadj_chain_kernel(const DadjAr
   if (S > 1) issue(1);
   __syncthreads();
   const int bpos = wave * V + min(lr, V - 1);          // this lane's column of the frame (padding lanes: clamped)
+  // x operands of the reduction epilogue (raw loads, row u = lane, channel c_j + 4h of tile tm); tile 0 is fetched
+  // under the last stage of the main loop so that its latency is hidden
+  const float* xr = a.x + ((long)n * a.C + c0) * P + (long)min(t, T - 1) * V + min(lr, V - 1);
+  auto load_x = [&](int tm, float (&xa)[16]) __attribute__((always_inline)) {
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+      const int c = tm * 32 + (j & 3) + 8 * (j >> 2) + 4 * h;
+      xa[j] = xr[(long)min(c0 + c, a.C - 1) * P - (long)c0 * P];
+    }
+  };
+  float xa0[16];
   for (int s = 0; s < S; ++s) {
     if (s + 1 < S) commit(s + 1);
     if (s + 2 < S) issue(s + 2);
+    if (s == S - 1) load_x(0, xa0);
     if (fvalid) {
       const unsigned char* ab = abuf + (s & 1) * A_IMG + lane * 16;
       const unsigned char* bb = bbuf + (s & 1) * B_IMG;
@@ -580,17 +592,15 @@ __global__ void __launch_bounds__(NW * 64, 2) gcn_dadj_chain_kernel(const DadjAr
 #pragma unroll
   for (int j = 0; j < 16; ++j) d[j] = 0.f;
   if (fvalid) {
-    const float* xr = a.x + ((long)n * a.C + c0) * P + (long)t * V + min(lr, V - 1);
+    float xb[2][16];
 #pragma unroll
     for (int tm = 0; tm < TM; ++tm) {
-      float xa[16];
+      if (tm + 1 < TM) load_x(tm + 1, xb[(tm + 1) & 1]);          // next tile's operands in flight during this tile
 #pragma unroll
       for (int j = 0; j < 16; ++j) {
-        const int c = tm * 32 + (j & 3) + 8 * (j >> 2) + 4 * h;
-        xa[j] = xr[(long)min(c0 + c, a.C - 1) * P - (long)c0 * P];
+        const float xv = (tm == 0) ? xa0[j] : xb[tm & 1][j];
+        d = mfma32((lr < V) ? xv : 0.f, acc[tm][j], d);
       }
-#pragma unroll
-      for (int j = 0; j < 16; ++j) d = mfma32((lr < V) ? xa[j] : 0.f, acc[tm][j], d);
     }
   }
   // ---- sum the NW frames of the tile and store the slot ----
