@@ -43,6 +43,7 @@ extern "C" int agcn_colsum(const float* X, int nslots, int W, void* scratch, flo
 
 // split-bf16 temporal convolution (conv_gemm_bf16.hip); npl: 3 = bf16x6 (fp32-equivalent), 2 = bf16x3
 size_t agcn_bf16_conv_workspace(int Cin, int Cout, int T, int V, int stride);
+bool agcn_bf16_conv_wide(int taps, int M);
 int agcn_bf16_conv9_fwd(const float* x, const float* w, const float* bias, float* y, float* stats_part, void* ws,
                         size_t ws_bytes, int N, int Cin, int Cout, int T, int V, int stride, int npl, hipStream_t s);
 int agcn_bf16_conv9_bwd_data(const float* dy, const float* w, float* dx, int accumulate, const float* add1,

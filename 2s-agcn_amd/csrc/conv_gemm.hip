@@ -559,6 +559,16 @@ int agcn_conv_num_tiles(int V, int T_out) {
   int tt = agcn_conv_tile_frames(V, T_out);
   return (T_out + tt - 1) / tt;
 }
+// slots per sample of the (sum, sumsq) partials agcn_conv_fwd writes for these sizes (depends on the kernel picked)
+int agcn_conv_stats_tiles(int Cin, int Cout, int T_out, int V, int taps, int stride) {
+  (void)Cin; (void)stride;
+  if (taps == 9 && agcn_gemm_precision() == 3 && Cout % 128 != 0 && agcn_bf16_conv_wide(taps, Cout)) {
+    int tt = 512 / V;
+    if (tt > T_out) tt = T_out;
+    return (T_out + tt - 1) / tt;
+  }
+  return agcn_conv_num_tiles(V, T_out);
+}
 int agcn_dadj_num_slots(int C, int V, int T) {
   if (agcn_gemm_precision() == 3 && agcn_gcn_dadj_chain_supported(C, V)) return agcn_gcn_dadj_chain_slots(C, T);
   int tt = 128 / V;

@@ -97,7 +97,9 @@ __global__ void __launch_bounds__(256) pack_weights_bf16_kernel(const BfPackArgs
 }
 
 // NPL = 3: bf16x6 (fp32-equivalent) ; NPL = 2: bf16x3.  WQ = 64-row blocks per staging quarter (2: windows <= 512 rows)
-template <int TAPS, int NPL, int WQ, int TM>
+// TN = 32-position tiles per wave (2: 64-row blocks cover 512 positions, so every weight fragment feeds two MFMAs and
+// the 8-frame halo of the window is amortised over 20 frames instead of 10)
+template <int TAPS, int NPL, int WQ, int TM, int TN = 1>
 __global__ void __launch_bounds__(NT, (TAPS == 1 && TM == 2) ? 4 : 2) conv_gemm_bf16_kernel(const BfArgs a) {
   constexpr int BM = TM * 32;
   constexpr int A_PLANE = TAPS * 2 * BM * 16;          // bytes per plane of the A image
@@ -123,20 +125,25 @@ __global__ void __launch_bounds__(NT, (TAPS == 1 && TM == 2) ? 4 : 2) conv_gemm_
   const int WL = a.FW * V, WLR = a.WLR;
   const int g0 = f0 * V;
 
-  int q = wave * 32 + lr;                 // this wave's 32 positions
-  if (q >= ttv) q = 0;
-  const int tl = q / V, v = q - tl * V;
-  const int boff = tl * a.src_stride * V + v;
-  const int ooff = ((t0 + tl) * a.out_fs + a.out_fo) * V + v;
+  int boff[TN];                           // this wave's TN x 32 positions
+#pragma unroll
+  for (int tn = 0; tn < TN; ++tn) {
+    int q = (wave * TN + tn) * 32 + lr;
+    if (q >= ttv) q = 0;
+    const int tl = q / V;
+    boff[tn] = tl * a.src_stride * V + (q - tl * V);
+  }
 
   float* bias_s = reinterpret_cast<float*>(smem + a.off_bias);   // beyond everything the epilogue tile overwrites
   for (int e = tid; e < BM; e += NT) bias_s[e] = (a.bias && m0 + e < a.M) ? a.bias[m0 + e] : 0.f;
 
-  f32x16 acc[TM];
+  f32x16 acc[TM][TN];
 #pragma unroll
   for (int tm = 0; tm < TM; ++tm)
 #pragma unroll
-    for (int j = 0; j < 16; ++j) acc[tm][j] = 0.f;
+    for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+      for (int j = 0; j < 16; ++j) acc[tm][tn][j] = 0.f;
 
   // staging roles: wave -> (channel half hb, window quarter wq)
   const int hb = wave & 1, wq = wave >> 1;
@@ -200,45 +207,49 @@ __global__ void __launch_bounds__(NT, (TAPS == 1 && TM == 2) ? 4 : 2) conv_gemm_
     __syncthreads();
 #pragma unroll 1
     for (int tap = 0; tap < TAPS; ++tap) {
-      bf16x8 af[NPL][TM], bf[NPL];
+      bf16x8 af[NPL][TM], bf[NPL][TN];
 #pragma unroll
       for (int pl = 0; pl < NPL; ++pl) {
 #pragma unroll
         for (int tm = 0; tm < TM; ++tm)
           af[pl][tm] = *reinterpret_cast<const bf16x8*>(Ab + pl * A_PLANE + (((tap * 2 + h) * BM) + tm * 32 + lr) * 16);
-        bf[pl] = *reinterpret_cast<const bf16x8*>(Bb + ((pl * 2 + h) * WLR + boff + tap * V) * 16);
+#pragma unroll
+        for (int tn = 0; tn < TN; ++tn)
+          bf[pl][tn] = *reinterpret_cast<const bf16x8*>(Bb + ((pl * 2 + h) * WLR + boff[tn] + tap * V) * 16);
       }
 #pragma unroll
-      for (int tm = 0; tm < TM; ++tm) {
-        // smallest products first
-        if (NPL == 3) {
-          acc[tm] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[2][tm], bf[0], acc[tm], 0, 0, 0);
-          acc[tm] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0][tm], bf[2], acc[tm], 0, 0, 0);
-          acc[tm] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1][tm], bf[1], acc[tm], 0, 0, 0);
+      for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+        for (int tn = 0; tn < TN; ++tn) {
+          // smallest products first
+          if (NPL == 3) {
+            acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[2][tm], bf[0][tn], acc[tm][tn], 0, 0, 0);
+            acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0][tm], bf[2][tn], acc[tm][tn], 0, 0, 0);
+            acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1][tm], bf[1][tn], acc[tm][tn], 0, 0, 0);
+          }
+          acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1][tm], bf[0][tn], acc[tm][tn], 0, 0, 0);
+          acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0][tm], bf[1][tn], acc[tm][tn], 0, 0, 0);
+          acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0][tm], bf[0][tn], acc[tm][tn], 0, 0, 0);
         }
-        acc[tm] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1][tm], bf[0], acc[tm], 0, 0, 0);
-        acc[tm] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0][tm], bf[1], acc[tm], 0, 0, 0);
-        acc[tm] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0][tm], bf[0], acc[tm], 0, 0, 0);
-      }
     }
   }
 
   // ---- epilogue (epilogue.h): tile -> LDS -> coalesced row stores, residual operands, (sum, sumsq) partials ----
   __syncthreads();                                     // every wave is done with the A/B images
   float* tile = reinterpret_cast<float*>(smem);        // [BM][TP]
-  const int TP = NW * 32 + 1;
+  const int TP = NW * TN * 32 + 1;
   float* red = tile + BM * TP;                         // [NT * 2]
-  {
-    const int q = wave * 32 + lr;
 #pragma unroll
-    for (int tm = 0; tm < TM; ++tm)
+  for (int tm = 0; tm < TM; ++tm)
 #pragma unroll
-      for (int j = 0; j < 16; ++j) tile[(tm * 32 + mfma_row(j, h)) * TP + q] = acc[tm][j];
-  }
+    for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+      for (int j = 0; j < 16; ++j)
+        tile[(tm * 32 + mfma_row(j, h)) * TP + (wave * TN + tn) * 32 + lr] = acc[tm][tn][j];
   __syncthreads();
-  int poff[4];
+  int poff[4 * TN];
 #pragma unroll
-  for (int u = 0; u < 4; ++u) {
+  for (int u = 0; u < 4 * TN; ++u) {
     const int q2 = lane + 64 * u;
     const int tl2 = q2 / V;
     poff[u] = tl2 * a.out_fs * V + (q2 - tl2 * V);
@@ -248,7 +259,7 @@ __global__ void __launch_bounds__(NT, (TAPS == 1 && TM == 2) ? 4 : 2) conv_gemm_
   ep.accumulate = a.accumulate;
   const long Pfull = (long)a.T_full * V;
   const long rows0 = (long)n * a.M * Pfull + ((long)t0 * a.out_fs + a.out_fo) * V;
-  epilogue_rows<BM, NW, 4>(ep, tile, TP, bias_s, red, a.M, m0, rows0, Pfull, nvalid, poff, (long)n * a.ntiles + tile_id);
+  epilogue_rows<BM, NW, 4 * TN>(ep, tile, TP, bias_s, red, a.M, m0, rows0, Pfull, nvalid, poff, (long)n * a.ntiles + tile_id);
 }
 
 struct BfGeom {
@@ -256,10 +267,10 @@ struct BfGeom {
   size_t smem_bytes, pack_bytes;
 };
 
-template <int TAPS, int BM>
+template <int TAPS, int BM, int TN = 1>
 BfGeom bf_geometry(int V, int T_out, int src_stride, int M, int Kinner) {
   BfGeom g;
-  g.tt = 256 / V;
+  g.tt = (256 * TN) / V;
   if (g.tt > T_out) g.tt = T_out;
   if (g.tt < 1) g.tt = 1;
   g.ntiles = (T_out + g.tt - 1) / g.tt;
@@ -271,7 +282,7 @@ BfGeom bf_geometry(int V, int T_out, int src_stride, int M, int Kinner) {
   g.off_b = (int)a_bytes;
   const size_t b_bytes = (size_t)3 * 2 * g.WLR * 16;
   size_t main_b = a_bytes + b_bytes;
-  size_t epi_b = (size_t)BM * (NW * 32 + 1) * 4 + (size_t)NT * 2 * 4;
+  size_t epi_b = (size_t)BM * (NW * TN * 32 + 1) * 4 + (size_t)NT * 2 * 4;
   g.smem_bytes = ((main_b > epi_b ? main_b : epi_b) + 15) & ~(size_t)15;
   g.off_bias = (int)g.smem_bytes;
   g.smem_bytes += (size_t)BM * 4;
@@ -288,11 +299,11 @@ struct BfProblem {
   size_t ws_bytes;
 };
 
-template <int TAPS, int NPL, int WQ, int TM>
+template <int TAPS, int NPL, int WQ, int TM, int TN = 1>
 int launch_bf(BfProblem& p, hipStream_t stream) {
   constexpr int BM = TM * 32;
   BfArgs a = p.a;
-  const BfGeom g = bf_geometry<TAPS, BM>(a.V, a.T_out, a.src_stride, a.M, a.Kinner);
+  const BfGeom g = bf_geometry<TAPS, BM, TN>(a.V, a.T_out, a.src_stride, a.M, a.Kinner);
   if (g.smem_bytes > 160 * 1024) return AGCN_ERR_UNSUPPORTED;
   if ((g.FW * a.V + 3) / 4 > WQ * 64) return AGCN_ERR_UNSUPPORTED;
   if (g.pack_bytes > p.ws_bytes) return AGCN_ERR_WORKSPACE;
@@ -308,7 +319,7 @@ int launch_bf(BfProblem& p, hipStream_t stream) {
     int rc = agcn_check_launch();
     if (rc) return rc;
   }
-  auto kern = conv_gemm_bf16_kernel<TAPS, NPL, WQ, TM>;
+  auto kern = conv_gemm_bf16_kernel<TAPS, NPL, WQ, TM, TN>;
   static bool attr_set = false;
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
@@ -327,10 +338,21 @@ int launch_npl(BfProblem& p, int npl, hipStream_t s) {
                        160 * 1024;
   if (p.a.M % 128 == 0 && fits128)
     return npl == 2 ? launch_bf<TAPS, 2, WQ, 4>(p, s) : launch_bf<TAPS, 3, WQ, 4>(p, s);
+  if (agcn_bf16_conv_wide(TAPS, p.a.M) && npl == 3) return launch_bf<TAPS, 3, 3, 2, 2>(p, s);
   return npl == 2 ? launch_bf<TAPS, 2, WQ, 2>(p, s) : launch_bf<TAPS, 3, WQ, 2>(p, s);
 }
 
 }  // namespace
+
+// 64-row problems with taps: 2 position tiles per wave (512-position workgroup tiles).  AGCN_CONV_WIDE=0 disables.
+bool agcn_bf16_conv_wide(int taps, int M) {
+  static int v = -1;
+  if (v < 0) {
+    const char* e = getenv("AGCN_CONV_WIDE");
+    v = (e && atoi(e) == 0) ? 0 : 1;
+  }
+  return v == 1 && taps > 1 && M <= 64;
+}
 
 // internal entry points used by conv_gemm.hip's dispatch (precision: 3 = bf16x6, 2 = bf16x3)
 size_t agcn_bf16_conv_workspace(int Cin, int Cout, int T, int V, int stride) {

@@ -29,7 +29,7 @@ __device__ __forceinline__ void epilogue_rows(const EpiPtrs& e, const float* til
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   // Row groups are software-pipelined: the operands of group k+1 are loaded RAW into registers while group k is
   // combined and stored.
-  constexpr int RG = (XB >= 4) ? 2 : 4, NG = BM / (NW * RG);   // rows in flight per wave (register budget)
+  constexpr int RG = (XB >= 8) ? 1 : ((XB >= 4) ? 2 : 4), NG = BM / (NW * RG);   // rows in flight per wave (register budget)
   static_assert(BM % (NW * RG) == 0, "row groups must tile the block");
   const bool has_extra = e.accumulate || e.add1 || e.add2;   // kernel-uniform
   float ex[2][5][RG][XB];                                    // [buffer][out, add1, mask1, add2, mask2]

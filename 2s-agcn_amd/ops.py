@@ -61,7 +61,7 @@ def conv_fwd(x, w, b, stride=1, want_stats=False):
     y = _empty((N, Cout, To, V), x)
     stats = None
     if want_stats:
-        nt = _L().agcn_conv_num_tiles(V, To)
+        nt = _L().agcn_conv_stats_tiles(Cin, Cout, To, V, taps, stride)
         stats = _empty((N * nt, 2, Cout), x)
     ws, nb = _conv_ws(Cin, Cout, T, V, taps, stride, x)
     _lib.check(_L().agcn_conv_fwd(_lib.ptr(x), _lib.ptr(w), _lib.ptr(b), _lib.ptr(y), _lib.ptr(stats), ws.data_ptr(),

@@ -39,7 +39,8 @@ const char* agcn_arch(void);     /* "gfx950" */
 
 /* ---- tile geometry queries (sizes of the partial slabs below) ---------------------------------------------------- */
 int agcn_conv_tile_frames(int V, int T_out);     /* frames per position tile of the contraction kernels (256/V) */
-int agcn_conv_num_tiles(int V, int T_out);       /* tiles per sample -> stats_part has N*num_tiles slots */
+int agcn_conv_num_tiles(int V, int T_out);       /* default tiles per sample */
+int agcn_conv_stats_tiles(int Cin, int Cout, int T_out, int V, int taps, int stride);   /* agcn_conv_fwd: stats_part has N * this many slots */
 int agcn_scores_num_tiles(int V, int T);         /* tiles per sample of the adjacency-score kernels */
 int agcn_dadj_num_slots(int C, int V, int T);    /* slots per (sample, subset) of the adjacency-gradient slab */
 

