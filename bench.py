@@ -91,7 +91,7 @@ def dominant_kernel_roofline(device, reps=10):
         kernel, peak, note = 'conv_gemm_kernel<9,0,2,4,2,2,8,11,0>', PEAK_FP32_MFMA_TFLOPS, 'f32 MFMA'
     else:
         products = 3 if mode == 'bf16x3' else 6
-        kernel = 'conv_gemm_bf16_kernel<9,%d,2,4>' % (2 if mode == 'bf16x3' else 3)
+        kernel = 'conv_gemm_bf16_kernel<9,%d,2,4,1>' % (2 if mode == 'bf16x3' else 3)
         peak = round(PEAK_BF16_MFMA_TFLOPS / products, 1)
         note = f'{products} bf16 MFMA products per fp32 product: peak = {PEAK_BF16_MFMA_TFLOPS:.0f}/{products}'
     traffic = None
