@@ -49,9 +49,10 @@ __device__ __forceinline__ int wc_joint(int ks, int h, int e) {
 }
 
 // TM: 32-row tiles of o per workgroup (BM = 32*TM); NCB: channel blocks (waves) per workgroup; VS: aggregation steps
-template <int AGG, int TM, int NCB, int VS>
-__global__ void __launch_bounds__(512, 2) wgrad_chain_kernel(const WcArgs a) {
-  constexpr int NW = 8, NT = 512, BM = TM * 32;
+// NW = waves per workgroup: 8 (one workgroup per CU) or 4 (two per CU, which overlap each other's staging and barriers)
+template <int AGG, int TM, int NCB, int VS, int NW = 8>
+__global__ void __launch_bounds__(NW * 64, 2) wgrad_chain_kernel(const WcArgs a) {
+  constexpr int NT = NW * 64, BM = TM * 32;
   constexpr int NFG = NW / NCB;                 // frame groups
   constexpr int FPW = (NCB <= 2) ? 1 : 2;       // frames per wave per stage
   constexpr int FT = NFG * FPW;                 // frames per stage
@@ -247,9 +248,9 @@ struct WcGeom {
   size_t smem_bytes;
 };
 
-template <int AGG, int TM, int NCB>
+template <int AGG, int TM, int NCB, int NW = 8>
 WcGeom wc_geom(int N, int M, int C, int V, int T_out) {
-  constexpr int BM = TM * 32, NFG = 8 / NCB, FPW = (NCB <= 2) ? 1 : 2, FT = NFG * FPW, CG = NCB * 32;
+  constexpr int BM = TM * 32, NFG = NW / NCB, FPW = (NCB <= 2) ? 1 : 2, FT = NFG * FPW, CG = NCB * 32;
   WcGeom g;
   g.ntiles = (T_out + FT - 1) / FT;
   g.ncg = (C + CG - 1) / CG;
@@ -258,7 +259,7 @@ WcGeom wc_geom(int N, int M, int C, int V, int T_out) {
   g.smem_bytes = (size_t)3 * FT * 4 * BM * 16 + (size_t)CG * g.XP * 4 + (AGG ? 32 * 32 * 4 : 0);
   g.grid_x = g.nmb * g.ncg * (AGG ? 3 : 1);
   const int pairs = N * g.ntiles;
-  int want = 256 / g.grid_x;             // one 8-wave workgroup per CU
+  int want = (256 * 8 / NW) / g.grid_x;  // one 8-wave (or two 4-wave) workgroups per CU
   if (want < 1) want = 1;
   if (want > pairs) want = pairs;
   g.pairs_per_split = (pairs + want - 1) / want;
@@ -267,14 +268,14 @@ WcGeom wc_geom(int N, int M, int C, int V, int T_out) {
   return g;
 }
 
-template <int AGG, int TM, int NCB, int VS>
+template <int AGG, int TM, int NCB, int VS, int NW = 8>
 int wc_launch(WcArgs a, void* ws, size_t ws_bytes, int* nslabs_out, hipStream_t stream) {
-  const WcGeom g = wc_geom<AGG, TM, NCB>(a.N, a.M, a.C, a.V, a.T_out);
+  const WcGeom g = wc_geom<AGG, TM, NCB, NW>(a.N, a.M, a.C, a.V, a.T_out);
   if (g.smem_bytes > 160 * 1024) return AGCN_ERR_UNSUPPORTED;
   if ((size_t)g.nslabs * a.wsize * 4 > ws_bytes) return AGCN_ERR_WORKSPACE;
   a.part = (float*)ws;
   a.ntiles = g.ntiles; a.pairs_per_split = g.pairs_per_split; a.ncg = g.ncg; a.XP = g.XP;
-  auto kern = wgrad_chain_kernel<AGG, TM, NCB, VS>;
+  auto kern = wgrad_chain_kernel<AGG, TM, NCB, VS, NW>;
   static bool attr_set = false;
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
@@ -282,7 +283,7 @@ int wc_launch(WcArgs a, void* ws, size_t ws_bytes, int* nslabs_out, hipStream_t 
     if (e != hipSuccess) return (int)e;
     attr_set = true;
   }
-  hipLaunchKernelGGL(kern, dim3(g.grid_x, g.nsplit), dim3(512), g.smem_bytes, stream, a);
+  hipLaunchKernelGGL(kern, dim3(g.grid_x, g.nsplit), dim3(NW * 64), g.smem_bytes, stream, a);
   *nslabs_out = g.nslabs;
   return agcn_check_launch();
 }
@@ -296,8 +297,29 @@ int wc_dispatch_vs(const WcArgs& a, void* ws, size_t ws_bytes, int* nslabs, hipS
   return wc_launch<AGG, TM, NCB, 16>(a, ws, ws_bytes, nslabs, s);
 }
 
+static inline bool wc_four_waves() {
+  static int v = -1;
+  if (v < 0) {
+    const char* e = getenv("AGCN_WGRAD_NW");
+    v = (e && atoi(e) == 8) ? 0 : 1;
+  }
+  return v == 1;
+}
+
+template <int AGG, int TM, int NCB, int NW>
+int wc_dispatch_vs4(const WcArgs& a, void* ws, size_t ws_bytes, int* nslabs, hipStream_t s) {
+  const int vs = (a.V + 1) / 2;
+  if (!AGG) return wc_launch<AGG, TM, NCB, 1, NW>(a, ws, ws_bytes, nslabs, s);
+  if (vs == 13) return wc_launch<AGG, TM, NCB, 13, NW>(a, ws, ws_bytes, nslabs, s);
+  if (vs == 9) return wc_launch<AGG, TM, NCB, 9, NW>(a, ws, ws_bytes, nslabs, s);
+  return wc_launch<AGG, TM, NCB, 16, NW>(a, ws, ws_bytes, nslabs, s);
+}
+
 template <int AGG, int TM>
 int wc_dispatch_ncb(const WcArgs& a, void* ws, size_t ws_bytes, int* nslabs, hipStream_t s) {
+  // (the aggregated variant at 128+ channels runs out of registers with 4-wave workgroups: measured 8 % slower)
+  if (wc_four_waves() && !AGG && a.C % 128 == 0) return wc_dispatch_vs4<AGG, TM, 4, 4>(a, ws, ws_bytes, nslabs, s);
+  if (wc_four_waves() && a.C % 64 == 0 && !(AGG && a.C % 128 == 0)) return wc_dispatch_vs4<AGG, TM, 2, 4>(a, ws, ws_bytes, nslabs, s);
   if (a.C % 256 == 0) return wc_dispatch_vs<AGG, TM, 8>(a, ws, ws_bytes, nslabs, s);
   if (a.C % 128 == 0) return wc_dispatch_vs<AGG, TM, 4>(a, ws, ws_bytes, nslabs, s);
   if (a.C % 64 == 0) return wc_dispatch_vs<AGG, TM, 2>(a, ws, ws_bytes, nslabs, s);
@@ -308,7 +330,9 @@ template <int AGG>
 size_t wc_slabs(int N, int M, int C, int V, int T_out) {
   const bool tm4 = M > 64 && C % 64 == 0;     // the single-block (few channels) variant stages 8 frames: 64 rows only
   int n;
-  if (C % 256 == 0) n = tm4 ? wc_geom<AGG, 4, 8>(N, M, C, V, T_out).nslabs : wc_geom<AGG, 2, 8>(N, M, C, V, T_out).nslabs;
+  if (wc_four_waves() && !AGG && C % 128 == 0) n = tm4 ? wc_geom<AGG, 4, 4, 4>(N, M, C, V, T_out).nslabs : wc_geom<AGG, 2, 4, 4>(N, M, C, V, T_out).nslabs;
+  else if (wc_four_waves() && C % 64 == 0 && !(AGG && C % 128 == 0)) n = tm4 ? wc_geom<AGG, 4, 2, 4>(N, M, C, V, T_out).nslabs : wc_geom<AGG, 2, 2, 4>(N, M, C, V, T_out).nslabs;
+  else if (C % 256 == 0) n = tm4 ? wc_geom<AGG, 4, 8>(N, M, C, V, T_out).nslabs : wc_geom<AGG, 2, 8>(N, M, C, V, T_out).nslabs;
   else if (C % 128 == 0) n = tm4 ? wc_geom<AGG, 4, 4>(N, M, C, V, T_out).nslabs : wc_geom<AGG, 2, 4>(N, M, C, V, T_out).nslabs;
   else if (C % 64 == 0) n = tm4 ? wc_geom<AGG, 4, 2>(N, M, C, V, T_out).nslabs : wc_geom<AGG, 2, 2>(N, M, C, V, T_out).nslabs;
   else n = tm4 ? wc_geom<AGG, 4, 1>(N, M, C, V, T_out).nslabs : wc_geom<AGG, 2, 1>(N, M, C, V, T_out).nslabs;
