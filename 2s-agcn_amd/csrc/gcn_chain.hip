@@ -703,12 +703,14 @@ int agcn_gcn_chain(int mode, const float* in, const float* adj, const float* wca
 }
 
 // ---- adjacency gradient (gcn_dadj_chain_kernel): C a multiple of 64; row block 128 when C is a multiple of 128 ----
-constexpr int DADJ_NW = 8;
+constexpr int DADJ_NW = 8;    // 128-row blocks: 8 frames per workgroup (one per CU)
+constexpr int DADJ_NW64 = 4;  // 64-row blocks: 4 frames, two workgroups per CU
 bool agcn_gcn_dadj_chain_supported(int C, int V) { return C >= 64 && C % 64 == 0 && V <= 32; }
 
 int agcn_gcn_dadj_chain_slots(int C, int T) {
   const int bm = (C % 128 == 0) ? 128 : 64;
-  return ((T + DADJ_NW - 1) / DADJ_NW) * (C / bm);
+  const int nw = (bm == 128) ? DADJ_NW : DADJ_NW64;
+  return ((T + nw - 1) / nw) * (C / bm);
 }
 
 size_t agcn_gcn_dadj_chain_workspace(int C, int Cout) {
@@ -721,5 +723,5 @@ int agcn_gcn_dadj_chain(const float* dy, const float* wcat, const float* x, floa
   DadjArgs a = {};
   a.dy = dy; a.x = x; a.dpart = dadj_part; a.N = N; a.C = C; a.Cout = Cout; a.T = T; a.V = V;
   if (C % 128 == 0) return dadj_chain_launch<4, DADJ_NW>(a, wcat, ws, ws_bytes, stream);
-  return dadj_chain_launch<2, DADJ_NW>(a, wcat, ws, ws_bytes, stream);
+  return dadj_chain_launch<2, DADJ_NW64>(a, wcat, ws, ws_bytes, stream);
 }

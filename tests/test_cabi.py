@@ -37,7 +37,7 @@ def test_library_loads_and_exports_every_symbol():
     assert L.agcn_conv_tile_frames(25, 300) == 10 and L.agcn_conv_num_tiles(25, 300) == 30
     assert L.agcn_conv_num_tiles(18, 300) == 22 and L.agcn_scores_num_tiles(25, 75) == 8
     assert L.agcn_dadj_num_slots(3, 25, 300) == 60          # f32 path: 5-frame tiles
-    assert L.agcn_dadj_num_slots(64, 25, 300) in (38, 60)   # chained bf16x6 path: 8-frame tiles (AGCN_GEMM default)
+    assert L.agcn_dadj_num_slots(64, 25, 300) in (75, 60)   # chained bf16x6 path: 4-frame tiles at 64 channels (AGCN_GEMM default)
     assert L.agcn_conv_bwd_weight_workspace(128, 64, 64, 300, 25, 9, 1) > 0
 
 
