@@ -93,7 +93,7 @@ __device__ __forceinline__ f32x16 agg_chain(const float* bxrow, const float* adj
 
 // WB = max number of 64-float column blocks of a staged window row (compile-time bound of the prefetch registers)
 template <int TAPS, int AGG, int WM, int WN, int TM, int TN, int CK, int WB, int EPI>
-__global__ void __launch_bounds__(WM* WN * 64, (TAPS == 1 && EPI == 0) ? 4 : 2) conv_gemm_kernel(const ConvGemmArgs a) {
+__global__ void __launch_bounds__(WM* WN * 64, (TAPS == 1 && EPI == 0 && (AGG == 0 || WM * WN == 8) && (WB < 8 || WM * WN == 8)) ? 4 : 2) conv_gemm_kernel(const ConvGemmArgs a) {
   constexpr int NW = WM * WN, NT = NW * 64;
   constexpr int BM = WM * TM * 32;
   constexpr int NSUB = AGG ? 3 : 1;
