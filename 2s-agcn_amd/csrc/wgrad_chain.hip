@@ -291,10 +291,13 @@ int wc_launch(WcArgs a, void* ws, size_t ws_bytes, int* nslabs_out, hipStream_t 
 template <int AGG, int TM, int NCB>
 int wc_dispatch_vs(const WcArgs& a, void* ws, size_t ws_bytes, int* nslabs, hipStream_t s) {
   const int vs = (a.V + 1) / 2;
-  if (!AGG) return wc_launch<AGG, TM, NCB, 1>(a, ws, ws_bytes, nslabs, s);
-  if (vs == 13) return wc_launch<AGG, TM, NCB, 13>(a, ws, ws_bytes, nslabs, s);
-  if (vs == 9) return wc_launch<AGG, TM, NCB, 9>(a, ws, ws_bytes, nslabs, s);
-  return wc_launch<AGG, TM, NCB, 16>(a, ws, ws_bytes, nslabs, s);
+  if constexpr (!AGG) {
+    return wc_launch<AGG, TM, NCB, 1>(a, ws, ws_bytes, nslabs, s);
+  } else {
+    if (vs == 13) return wc_launch<AGG, TM, NCB, 13>(a, ws, ws_bytes, nslabs, s);
+    if (vs == 9) return wc_launch<AGG, TM, NCB, 9>(a, ws, ws_bytes, nslabs, s);
+    return wc_launch<AGG, TM, NCB, 16>(a, ws, ws_bytes, nslabs, s);
+  }
 }
 
 static inline bool wc_four_waves() {
@@ -309,10 +312,13 @@ static inline bool wc_four_waves() {
 template <int AGG, int TM, int NCB, int NW>
 int wc_dispatch_vs4(const WcArgs& a, void* ws, size_t ws_bytes, int* nslabs, hipStream_t s) {
   const int vs = (a.V + 1) / 2;
-  if (!AGG) return wc_launch<AGG, TM, NCB, 1, NW>(a, ws, ws_bytes, nslabs, s);
-  if (vs == 13) return wc_launch<AGG, TM, NCB, 13, NW>(a, ws, ws_bytes, nslabs, s);
-  if (vs == 9) return wc_launch<AGG, TM, NCB, 9, NW>(a, ws, ws_bytes, nslabs, s);
-  return wc_launch<AGG, TM, NCB, 16, NW>(a, ws, ws_bytes, nslabs, s);
+  if constexpr (!AGG) {
+    return wc_launch<AGG, TM, NCB, 1, NW>(a, ws, ws_bytes, nslabs, s);
+  } else {
+    if (vs == 13) return wc_launch<AGG, TM, NCB, 13, NW>(a, ws, ws_bytes, nslabs, s);
+    if (vs == 9) return wc_launch<AGG, TM, NCB, 9, NW>(a, ws, ws_bytes, nslabs, s);
+    return wc_launch<AGG, TM, NCB, 16, NW>(a, ws, ws_bytes, nslabs, s);
+  }
 }
 
 template <int AGG, int TM>
