@@ -29,6 +29,22 @@ def _no_gbn(gbn_split):
         raise NotImplementedError("agcn_amd.aagcn: GhostBatchNorm (gbn_split >= 2) is not supported")
 
 
+class _Gate(torch.autograd.Function):
+    """y = x * se + x with a broadcast gate se (reference aagcn.py:264-271), as one pass forward and three backward
+    (stock autograd spends 2 + 5 full-tensor passes on the same expression)."""
+
+    @staticmethod
+    def forward(ctx, x, se):
+        ctx.save_for_backward(x, se)
+        return torch.addcmul(x, x, se)
+
+    @staticmethod
+    def backward(ctx, g):
+        x, se = ctx.saved_tensors
+        g = g.contiguous()
+        return torch.addcmul(g, g, se), (g * x).sum_to_size(se.shape)
+
+
 class SpatialAttention(nn.Module):
     def __init__(self, in_channels: int, out_channels: int = 1, kernel_size: int = 9):
         super().__init__()
@@ -40,7 +56,7 @@ class SpatialAttention(nn.Module):
 
     def forward(self, x):
         se = self.sigmoid(self.conv_sa(x.mean(-2)))          # N 1 V
-        return x * se.unsqueeze(-2) + x
+        return _Gate.apply(x, se.unsqueeze(-2))
 
 
 class TemporalAttention(nn.Module):
@@ -54,7 +70,7 @@ class TemporalAttention(nn.Module):
 
     def forward(self, x):
         se = self.sigmoid(self.conv_ta(x.mean(-1)))          # N 1 T
-        return x * se.unsqueeze(-1) + x
+        return _Gate.apply(x, se.unsqueeze(-1))
 
 
 class ChannelAttention(nn.Module):
@@ -72,7 +88,7 @@ class ChannelAttention(nn.Module):
     def forward(self, x):
         se = self.relu(self.fc1c(x.mean(-1).mean(-1)))
         se = self.sigmoid(self.fc2c(se))
-        return x * se.unsqueeze(-1).unsqueeze(-1) + x
+        return _Gate.apply(x, se.unsqueeze(-1).unsqueeze(-1))
 
 
 class NonAdaptiveGCN(nn.Module):
