@@ -77,16 +77,20 @@ template <int RES, bool RELU>
 __global__ void __launch_bounds__(256)
 bn_act_fwd_kernel(const float4* __restrict__ y1, const float* __restrict__ scale1, const float* __restrict__ shift1,
                   const float4* __restrict__ r, const float* __restrict__ scale2, const float* __restrict__ shift2,
-                  float4* __restrict__ out, unsigned total4, unsigned P, unsigned C) {
-  for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += gridDim.x * blockDim.x) {
-    const unsigned e0 = i * 4u;
+                  float4* __restrict__ out, unsigned* __restrict__ bits, unsigned total4, unsigned P, unsigned C) {
+  // block-uniform trip count: the sign-mask words are assembled with shuffles over groups of 8 lanes (32 elements)
+  for (unsigned i0 = blockIdx.x * blockDim.x; i0 < total4; i0 += gridDim.x * blockDim.x) {
+    const unsigned i = i0 + threadIdx.x;
+    const bool valid = i < total4;
+    const unsigned ic = valid ? i : 0u;
+    const unsigned e0 = ic * 4u;
     const unsigned row = e0 / P;
     const unsigned rem = e0 - row * P;
     const unsigned c0 = row % C;
     const unsigned c1 = (c0 + 1 == C) ? 0u : c0 + 1;
-    const float4 a = y1[i];
+    const float4 a = y1[ic];
     float4 b = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (RES != 0) b = r[i];
+    if (RES != 0) b = r[ic];
     float av[4] = {a.x, a.y, a.z, a.w};
     float bv[4] = {b.x, b.y, b.z, b.w};
     float ov[4];
@@ -98,25 +102,40 @@ bn_act_fwd_kernel(const float4* __restrict__ y1, const float* __restrict__ scale
       if (RES == 2) v += scale2[c] * bv[k] + shift2[c];
       ov[k] = RELU ? fmaxf(v, 0.f) : v;
     }
-    out[i] = make_float4(ov[0], ov[1], ov[2], ov[3]);
+    if (valid) out[i] = make_float4(ov[0], ov[1], ov[2], ov[3]);
+    if (bits) {
+      // bit e of word w <-> element 32*w + e is positive: what every backward pass needs of `out`, 32x smaller
+      unsigned nib = valid ? ((ov[0] > 0.f) | ((ov[1] > 0.f) << 1) | ((ov[2] > 0.f) << 2) | ((ov[3] > 0.f) << 3)) : 0u;
+      unsigned w = nib << (4u * (threadIdx.x & 7u));
+      w |= __shfl_xor(w, 1);
+      w |= __shfl_xor(w, 2);
+      w |= __shfl_xor(w, 4);
+      if ((threadIdx.x & 7u) == 0u && valid) bits[e0 >> 5] = w;
+    }
   }
 }
 
 // per (n,c) row: s0 = sum dz, s1 = sum dz*y1, s2 = sum dz*y2, dz = dout * (mask > 0)
 template <bool HAS2>
 __global__ void __launch_bounds__(256)
-bn_bwd_reduce_kernel(const float* __restrict__ dout, const float* __restrict__ mask, const float* __restrict__ y1,
-                     const float* __restrict__ y2, float* __restrict__ part, int P) {
+bn_bwd_reduce_kernel(const float* __restrict__ dout, const float* __restrict__ mask, int mask_bits,
+                     const float* __restrict__ y1, const float* __restrict__ y2, float* __restrict__ part, int P) {
   __shared__ float red[3][4];
   const long row = blockIdx.x;
   const float* d = dout + row * P;
-  const float* mk = mask ? mask + row * P : nullptr;
+  const float* mk = (mask && !mask_bits) ? mask + row * P : nullptr;
+  const unsigned* mb = (mask && mask_bits) ? reinterpret_cast<const unsigned*>(mask) : nullptr;
+  const long e_row = row * P;
   const float* a = y1 + row * P;
   const float* b = HAS2 ? y2 + row * P : nullptr;
   float s0 = 0.f, s1 = 0.f, s2 = 0.f;
   for (int q = threadIdx.x; q < P; q += 256) {
     float dz = d[q];
     if (mk) dz = (mk[q] > 0.f) ? dz : 0.f;
+    if (mb) {
+      const long e = e_row + q;
+      dz = ((mb[e >> 5] >> (e & 31)) & 1u) ? dz : 0.f;
+    }
     s0 += dz;
     s1 += dz * a[q];
     if (HAS2) s2 += dz * b[q];
@@ -172,7 +191,8 @@ __global__ void bn_bwd_finalize_kernel(const float* __restrict__ part, int N, in
 
 template <bool HAS2>
 __global__ void __launch_bounds__(256)
-bn_bwd_apply_kernel(const float4* __restrict__ dout, const float4* __restrict__ mask, const float4* __restrict__ y1,
+bn_bwd_apply_kernel(const float4* __restrict__ dout, const float4* __restrict__ mask, int mask_bits,
+                    const float4* __restrict__ y1,
                     const float4* __restrict__ y2, const float* __restrict__ coef, float4* __restrict__ dy1,
                     float4* __restrict__ dy2, unsigned total4, unsigned P, unsigned C) {
   for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += gridDim.x * blockDim.x) {
@@ -185,11 +205,15 @@ bn_bwd_apply_kernel(const float4* __restrict__ dout, const float4* __restrict__ 
     const float4 a4 = y1[i];
     float dv[4] = {d4.x, d4.y, d4.z, d4.w};
     float av[4] = {a4.x, a4.y, a4.z, a4.w};
-    if (mask) {
+    if (mask && !mask_bits) {
       const float4 m4 = mask[i];
       const float mv[4] = {m4.x, m4.y, m4.z, m4.w};
 #pragma unroll
       for (int k = 0; k < 4; ++k) dv[k] = (mv[k] > 0.f) ? dv[k] : 0.f;
+    } else if (mask) {
+      const unsigned nib = reinterpret_cast<const unsigned*>(mask)[e0 >> 5] >> (e0 & 31u);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) dv[k] = ((nib >> k) & 1u) ? dv[k] : 0.f;
     }
     float bv[4] = {0.f, 0.f, 0.f, 0.f};
     if (HAS2) {
@@ -262,7 +286,8 @@ int agcn_bn_eval_coeff(const float* gamma, const float* beta, const float* runni
 
 // res_mode: 0 none, 1 identity residual r, 2 BN'd residual branch scale2*r+shift2 ; total = N*C*P must be %4
 int agcn_bn_act_fwd(const float* y1, const float* scale1, const float* shift1, const float* r, const float* scale2,
-                    const float* shift2, float* out, int N, int C, int P, int res_mode, int relu, void* stream) {
+                    const float* shift2, float* out, unsigned* sign_bits, int N, int C, int P, int res_mode, int relu,
+                    void* stream) {
   if (!y1 || !scale1 || !shift1 || !out || N <= 0 || C <= 0 || P <= 0) return AGCN_ERR_ARG;
   const long total = (long)N * C * P;
   if (total % 4 != 0 || total / 4 > 0x7fffffffL) return AGCN_ERR_UNSUPPORTED;
@@ -273,7 +298,7 @@ int agcn_bn_act_fwd(const float* y1, const float* scale1, const float* shift1, c
   const dim3 g(ew_grid(t4)), b(256);
 #define LAUNCH_ACT(R, A)                                                                                       \
   hipLaunchKernelGGL((bn_act_fwd_kernel<R, A>), g, b, 0, s, (const float4*)y1, scale1, shift1, (const float4*)r, \
-                     scale2, shift2, (float4*)out, t4, (unsigned)P, (unsigned)C)
+                     scale2, shift2, (float4*)out, sign_bits, t4, (unsigned)P, (unsigned)C)
   if (relu) {
     if (res_mode == 0) LAUNCH_ACT(0, true); else if (res_mode == 1) LAUNCH_ACT(1, true); else LAUNCH_ACT(2, true);
   } else {
@@ -290,17 +315,19 @@ int agcn_bn_act_fwd(const float* y1, const float* scale1, const float* shift1, c
 //   agcn_bn_bwd_apply : sums `nrows` rows of part per channel (fixed order), then the coefficients over `count`
 //                       elements and the element-wise pass; dgamma/dbeta are multiplied by param_grad_scale
 //                       (1/world when the sums are global, so that the gradient all-reduce average restores them).
-int agcn_bn_bwd_reduce(const float* dout, const float* mask, const float* y1, const float* y2, float* part, int N, int C,
-                       int P, void* stream) {
+int agcn_bn_bwd_reduce(const float* dout, const void* mask, int mask_bits, const float* y1, const float* y2, float* part,
+                       int N, int C, int P, void* stream) {
   if (!dout || !y1 || !part || N <= 0 || C <= 0 || P <= 0) return AGCN_ERR_ARG;
   hipStream_t s = (hipStream_t)stream;
-  if (y2) hipLaunchKernelGGL(bn_bwd_reduce_kernel<true>, dim3(N * C), dim3(256), 0, s, dout, mask, y1, y2, part, P);
-  else hipLaunchKernelGGL(bn_bwd_reduce_kernel<false>, dim3(N * C), dim3(256), 0, s, dout, mask, y1, y2, part, P);
+  if (y2) hipLaunchKernelGGL(bn_bwd_reduce_kernel<true>, dim3(N * C), dim3(256), 0, s, dout, (const float*)mask,
+                             mask_bits, y1, y2, part, P);
+  else hipLaunchKernelGGL(bn_bwd_reduce_kernel<false>, dim3(N * C), dim3(256), 0, s, dout, (const float*)mask,
+                          mask_bits, y1, y2, part, P);
   return agcn_check_launch();
 }
 
 int agcn_bn_bwd_apply(const float* part, int nrows, double count, float param_grad_scale, const float* dout,
-                      const float* mask, const float* y1, const float* gamma1, const float* mean1, const float* invstd1,
+                      const void* mask, int mask_bits, const float* y1, const float* gamma1, const float* mean1, const float* invstd1,
                       const float* y2, const float* gamma2, const float* mean2, const float* invstd2, float* coef,
                       float* dy1, float* dgamma1, float* dbeta1, float* dy2, float* dgamma2, float* dbeta2, int N, int C,
                       int P, void* stream) {
@@ -318,24 +345,24 @@ int agcn_bn_bwd_apply(const float* part, int nrows, double count, float param_gr
   const unsigned t4 = (unsigned)(total / 4);
   const dim3 g(ew_grid(t4)), b(256);
   if (y2)
-    hipLaunchKernelGGL(bn_bwd_apply_kernel<true>, g, b, 0, s, (const float4*)dout, (const float4*)mask,
+    hipLaunchKernelGGL(bn_bwd_apply_kernel<true>, g, b, 0, s, (const float4*)dout, (const float4*)mask, mask_bits,
                        (const float4*)y1, (const float4*)y2, (const float*)coef, (float4*)dy1, (float4*)dy2, t4,
                        (unsigned)P, (unsigned)C);
   else
-    hipLaunchKernelGGL(bn_bwd_apply_kernel<false>, g, b, 0, s, (const float4*)dout, (const float4*)mask,
+    hipLaunchKernelGGL(bn_bwd_apply_kernel<false>, g, b, 0, s, (const float4*)dout, (const float4*)mask, mask_bits,
                        (const float4*)y1, (const float4*)y2, (const float*)coef, (float4*)dy1, (float4*)dy2, t4,
                        (unsigned)P, (unsigned)C);
   return agcn_check_launch();
 }
 
 // both stages back to back (per-replica statistics).  part: (N*C*3) scratch, coef: (6*C) scratch.
-int agcn_bn_bwd(const float* dout, const float* mask, const float* y1, const float* gamma1, const float* mean1,
-                const float* invstd1, const float* y2, const float* gamma2, const float* mean2, const float* invstd2,
-                float* part, float* coef, float* dy1, float* dgamma1, float* dbeta1, float* dy2, float* dgamma2,
-                float* dbeta2, int N, int C, int P, void* stream) {
-  int rc = agcn_bn_bwd_reduce(dout, mask, y1, y2, part, N, C, P, stream);
+int agcn_bn_bwd(const float* dout, const void* mask, int mask_bits, const float* y1, const float* gamma1,
+                const float* mean1, const float* invstd1, const float* y2, const float* gamma2, const float* mean2,
+                const float* invstd2, float* part, float* coef, float* dy1, float* dgamma1, float* dbeta1, float* dy2,
+                float* dgamma2, float* dbeta2, int N, int C, int P, void* stream) {
+  int rc = agcn_bn_bwd_reduce(dout, mask, mask_bits, y1, y2, part, N, C, P, stream);
   if (rc) return rc;
-  return agcn_bn_bwd_apply(part, N, (double)N * (double)P, 1.0f, dout, mask, y1, gamma1, mean1, invstd1, y2, gamma2,
+  return agcn_bn_bwd_apply(part, N, (double)N * (double)P, 1.0f, dout, mask, mask_bits, y1, gamma1, mean1, invstd1, y2, gamma2,
                            mean2, invstd2, coef, dy1, dgamma1, dbeta1, dy2, dgamma2, dbeta2, N, C, P, stream);
 }
 

@@ -46,10 +46,10 @@ SIGNATURES = {
     "agcn_colsum": (_I, [_P, _I, _I, _P, _P, _P]),
     "agcn_bn_stats_finalize": (_I, [_P, _I, _I, _D, _P, _P, _P, _P, _F, _F, _P, _P, _P, _P, _P, _P]),
     "agcn_bn_eval_coeff": (_I, [_P, _P, _P, _P, _F, _I, _P, _P, _P]),
-    "agcn_bn_act_fwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
-    "agcn_bn_bwd": (_I, [_P] * 18 + [_I, _I, _I, _P]),
-    "agcn_bn_bwd_reduce": (_I, [_P] * 5 + [_I, _I, _I, _P]),
-    "agcn_bn_bwd_apply": (_I, [_P, _I, _D, _F] + [_P] * 17 + [_I, _I, _I, _P]),
+    "agcn_bn_act_fwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
+    "agcn_bn_bwd": (_I, [_P, _P, _I] + [_P] * 16 + [_I, _I, _I, _P]),
+    "agcn_bn_bwd_reduce": (_I, [_P, _P, _I, _P, _P, _P, _I, _I, _I, _P]),
+    "agcn_bn_bwd_apply": (_I, [_P, _I, _D, _F, _P, _P, _I] + [_P] * 15 + [_I, _I, _I, _P]),
     "agcn_sgd_step_workspace": (_Z, [ctypes.c_long]),
     "agcn_sgd_step": (_I, [_P, _P, _P, ctypes.c_long, _F, _F, _F, _I, _F, _F, _I, _P, _Z, _P, _P]),
 }
@@ -73,6 +73,15 @@ def load():
         fn.argtypes = args
     _lib = lib
     return lib
+
+
+def ptr_bits(t):
+    """Device pointer of an int32 sign-bit-mask tensor (None -> NULL)."""
+    if t is None:
+        return None
+    if not (t.is_cuda and t.is_contiguous() and t.dtype == torch.int32):
+        raise RuntimeError(f"agcn_amd: expected a contiguous int32 GPU tensor, got {t.dtype} on {t.device}")
+    return t.data_ptr()
 
 
 def ptr(t):

@@ -237,19 +237,23 @@ def bn_eval_coeffs(gamma, beta, running_mean, running_var, eps=BN_EPS):
     return st
 
 
-def bn_act_fwd(y1, st1, r=None, st2=None, relu=True):
-    """out = act(scale1*y1 + shift1 + res); res = 0 (r None) | r (st2 None) | scale2*r + shift2."""
+def bn_act_fwd(y1, st1, r=None, st2=None, relu=True, want_bits=False):
+    """out = act(scale1*y1 + shift1 + res); res = 0 (r None) | r (st2 None) | scale2*r + shift2.
+    want_bits: also return the sign bit mask of ``out`` (int32 words, 32 elements each) for the BatchNorm backward."""
     N, C, T, V = y1.shape
     out = torch.empty_like(y1)
+    bits = torch.empty((y1.numel() + 31) // 32, dtype=torch.int32, device=y1.device) if want_bits else None
     mode = 0 if r is None else (1 if st2 is None else 2)
     _lib.check(_L().agcn_bn_act_fwd(_lib.ptr(y1), _lib.ptr(st1.scale), _lib.ptr(st1.shift), _lib.ptr(r),
                                     _lib.ptr(st2.scale) if st2 else None, _lib.ptr(st2.shift) if st2 else None,
-                                    _lib.ptr(out), N, C, T * V, mode, int(relu), _lib.stream()), "agcn_bn_act_fwd")
-    return out
+                                    _lib.ptr(out), _lib.ptr_bits(bits), N, C, T * V, mode, int(relu), _lib.stream()),
+               "agcn_bn_act_fwd")
+    return (out, bits) if want_bits else out
 
 
 def bn_bwd(dout, mask, y1, gamma1, st1, y2=None, gamma2=None, st2=None):
-    """Backward through out = relu(bn1(y1) [+ bn2(y2)] [+ identity]) in train mode.
+    """Backward through out = relu(bn1(y1) [+ bn2(y2)] [+ identity]) in train mode.  ``mask``: the fp32 output tensor
+    (positive elements pass) or the int32 sign bit mask of ``bn_act_fwd(..., want_bits=True)``; None = no ReLU.
     Returns dy1, dgamma1, dbeta1, dy2, dgamma2, dbeta2 (branch-2 entries None without y2)."""
     N, C, T, V = y1.shape
     part = _empty((N * C * 3,), y1)
@@ -261,18 +265,20 @@ def bn_bwd(dout, mask, y1, gamma1, st1, y2=None, gamma2=None, st2=None):
         dy2 = torch.empty_like(y2)
         dg2, db2 = _empty((C,), y1), _empty((C,), y1)
     world = _SYNC_BN["world"]
+    mbits = int(mask is not None and mask.dtype == torch.int32)
+    mptr = _lib.ptr_bits(mask) if mbits else _lib.ptr(mask)
     if world <= 1:
         _lib.check(_L().agcn_bn_bwd(
-            _lib.ptr(dout), _lib.ptr(mask), _lib.ptr(y1), _lib.ptr(gamma1), _lib.ptr(st1.mean), _lib.ptr(st1.invstd),
+            _lib.ptr(dout), mptr, mbits, _lib.ptr(y1), _lib.ptr(gamma1), _lib.ptr(st1.mean), _lib.ptr(st1.invstd),
             _lib.ptr(y2), _lib.ptr(gamma2), _lib.ptr(st2.mean) if st2 else None, _lib.ptr(st2.invstd) if st2 else None,
             _lib.ptr(part), _lib.ptr(coef), _lib.ptr(dy1), _lib.ptr(dg1), _lib.ptr(db1), _lib.ptr(dy2), _lib.ptr(dg2),
             _lib.ptr(db2), N, C, T * V, _lib.stream()), "agcn_bn_bwd")
     else:
-        _lib.check(_L().agcn_bn_bwd_reduce(_lib.ptr(dout), _lib.ptr(mask), _lib.ptr(y1), _lib.ptr(y2), _lib.ptr(part),
-                                           N, C, T * V, _lib.stream()), "agcn_bn_bwd_reduce")
+        _lib.check(_L().agcn_bn_bwd_reduce(_lib.ptr(dout), mptr, mbits, _lib.ptr(y1), _lib.ptr(y2),
+                                           _lib.ptr(part), N, C, T * V, _lib.stream()), "agcn_bn_bwd_reduce")
         sums = _allreduce_sum(_colsum(part, N, 3 * C))
         _lib.check(_L().agcn_bn_bwd_apply(
-            _lib.ptr(sums), 1, float(N * T * V * world), 1.0 / world, _lib.ptr(dout), _lib.ptr(mask), _lib.ptr(y1),
+            _lib.ptr(sums), 1, float(N * T * V * world), 1.0 / world, _lib.ptr(dout), mptr, mbits, _lib.ptr(y1),
             _lib.ptr(gamma1), _lib.ptr(st1.mean), _lib.ptr(st1.invstd), _lib.ptr(y2), _lib.ptr(gamma2),
             _lib.ptr(st2.mean) if st2 else None, _lib.ptr(st2.invstd) if st2 else None, _lib.ptr(coef), _lib.ptr(dy1),
             _lib.ptr(dg1), _lib.ptr(db1), _lib.ptr(dy2), _lib.ptr(dg2), _lib.ptr(db2), N, C, T * V, _lib.stream()),
@@ -313,9 +319,10 @@ def gcn_forward(c, x, A, PA, wab, bab, wd, bd, bn, down, training, alpha=None, a
     if down is not None:
         dpre, st2 = conv_fwd(x, down[0], down[1], want_stats=training)
         bn2 = _bn_coeffs(training, st2, count, *down[2:])
-        out = bn_act_fwd(ypre, bn1, dpre, bn2, relu=True)
+        out, bits = bn_act_fwd(ypre, bn1, dpre, bn2, relu=True, want_bits=True)
     else:
-        out = bn_act_fwd(ypre, bn1, x, None, relu=True)
+        out, bits = bn_act_fwd(ypre, bn1, x, None, relu=True, want_bits=True)
+    c.g_bits = bits          # sign bit mask of `out` for the BatchNorm backward (32x less traffic than `out`)
     c.g_x, c.g_tp, c.g_P, c.g_adj, c.g_ypre, c.g_dpre, c.g_out = x, tp, P, adj, ypre, dpre, out
     c.g_bn1, c.g_bn2 = bn1, bn2
     c.g_params = (wab, wd, bn[0], down[0] if down is not None else None, down[2] if down is not None else None)
@@ -329,7 +336,7 @@ def gcn_backward(c, dout, extra_add=None, extra_mask=None):
     x, tp, P, adj, ypre, dpre, out = c.g_x, c.g_tp, c.g_P, c.g_adj, c.g_ypre, c.g_dpre, c.g_out
     wab, wd, gamma1, wdown, gamma2 = c.g_params
     Cout = wd.shape[0]
-    dypre, dg1, db1, ddpre, dg2, db2 = bn_bwd(dout, out, ypre, gamma1, c.g_bn1, dpre, gamma2, c.g_bn2)
+    dypre, dg1, db1, ddpre, dg2, db2 = bn_bwd(dout, c.g_bits, ypre, gamma1, c.g_bn1, dpre, gamma2, c.g_bn2)
     dwd = project_bwd_weight(dypre, x, adj, Cout)
     if dpre is None:      # identity `down`: dx += dout * (out > 0)
         dx = aggregate_project_bwd_data(dypre, adj, wd, x.shape, add1=dout, mask1=out, add2=extra_add,
@@ -360,13 +367,14 @@ def tcn_forward(c, g, w, b, bn, stride, res_x, res, relu, training):
     bn1 = _bn_coeffs(training, st, count, *bn)
     rpre = bn2 = None
     if res is None:
-        out = bn_act_fwd(zpre, bn1, None, None, relu=relu)
+        out, bits = bn_act_fwd(zpre, bn1, None, None, relu=relu, want_bits=True)
     elif isinstance(res, str):
-        out = bn_act_fwd(zpre, bn1, res_x, None, relu=relu)
+        out, bits = bn_act_fwd(zpre, bn1, res_x, None, relu=relu, want_bits=True)
     else:
         rpre, st2 = conv_fwd(res_x, res[0], res[1], stride, want_stats=training)
         bn2 = _bn_coeffs(training, st2, count, *res[2:])
-        out = bn_act_fwd(zpre, bn1, rpre, bn2, relu=relu)
+        out, bits = bn_act_fwd(zpre, bn1, rpre, bn2, relu=relu, want_bits=True)
+    c.t_bits = bits
     c.t_g, c.t_zpre, c.t_rpre, c.t_out, c.t_bn1, c.t_bn2 = g, zpre, rpre, out, bn1, bn2
     c.t_resx, c.t_res_identity = res_x, isinstance(res, str)
     c.t_params = (w, bn[0], res[0] if isinstance(res, tuple) else None, res[2] if isinstance(res, tuple) else None)
@@ -377,7 +385,7 @@ def tcn_forward(c, g, w, b, bn, stride, res_x, res, relu, training):
 def tcn_backward(c, dout):
     """Returns dg, dw, dgamma, dbeta, (drpre, dw_res, dgamma_res, dbeta_res)."""
     w, gamma1, wres, gamma2 = c.t_params
-    mask = c.t_out if c.t_relu else None
+    mask = c.t_bits if c.t_relu else None
     dzpre, dg1, db1, drpre, dg2, db2 = bn_bwd(dout, mask, c.t_zpre, gamma1, c.t_bn1, c.t_rpre, gamma2, c.t_bn2)
     dw = conv_bwd_weight(dzpre, c.t_g, w.shape, c.t_stride)
     dg = conv_bwd_data(dzpre, w, c.t_g.shape, c.t_stride)

@@ -110,23 +110,27 @@ int agcn_bn_stats_finalize(const float* stats_part, int nslots, int C, double co
                            float* scale, float* shift, void* stream);
 int agcn_bn_eval_coeff(const float* gamma, const float* beta, const float* running_mean, const float* running_var,
                        float eps, int C, float* scale, float* shift, void* stream);
-/* out = act(scale1[c]*y1 + shift1[c] + res); res_mode 0: none, 1: r, 2: scale2[c]*r + shift2[c]; N*C*P % 4 == 0 */
+/* out = act(scale1[c]*y1 + shift1[c] + res); res_mode 0: none, 1: r, 2: scale2[c]*r + shift2[c]; N*C*P % 4 == 0.
+ * sign_bits (optional, may be NULL): ceil(N*C*P/32) words, bit e of word w = (out[32*w + e] > 0): the ReLU mask the
+ * backward needs, 32x smaller than `out`. */
 int agcn_bn_act_fwd(const float* y1, const float* scale1, const float* shift1, const float* r, const float* scale2,
-                    const float* shift2, float* out, int N, int C, int P, int res_mode, int relu, void* stream);
-/* train-mode backward of out = relu(bn1(y1) [+ bn2(y2)] [+ identity]); mask = out (NULL: no ReLU);
+                    const float* shift2, float* out, unsigned* sign_bits, int N, int C, int P, int res_mode, int relu,
+                    void* stream);
+/* train-mode backward of out = relu(bn1(y1) [+ bn2(y2)] [+ identity]); mask (NULL: no ReLU) is either the fp32 `out`
+ * tensor (mask_bits = 0: positive elements pass) or the sign_bits of agcn_bn_act_fwd (mask_bits = 1);
  * part: scratch N*C*3 floats, coef: scratch 6*C floats */
 /* the two stages of agcn_bn_bwd, exposed so that a synchronised BatchNorm (reference utils/processor.py:295) can
  * all-reduce the per-channel sums between them: part is (N*C*3); apply sums `nrows` rows of it per channel, uses
  * `count` elements per channel and scales dgamma/dbeta by param_grad_scale. */
-int agcn_bn_bwd_reduce(const float* dout, const float* mask, const float* y1, const float* y2, float* part, int N, int C,
-                       int P, void* stream);
+int agcn_bn_bwd_reduce(const float* dout, const void* mask, int mask_bits, const float* y1, const float* y2, float* part,
+                       int N, int C, int P, void* stream);
 int agcn_bn_bwd_apply(const float* part, int nrows, double count, float param_grad_scale, const float* dout,
-                      const float* mask, const float* y1, const float* gamma1, const float* mean1, const float* invstd1,
-                      const float* y2, const float* gamma2, const float* mean2, const float* invstd2, float* coef,
+                      const void* mask, int mask_bits, const float* y1, const float* gamma1, const float* mean1,
+                      const float* invstd1, const float* y2, const float* gamma2, const float* mean2, const float* invstd2, float* coef,
                       float* dy1, float* dgamma1, float* dbeta1, float* dy2, float* dgamma2, float* dbeta2, int N, int C,
                       int P, void* stream);
-int agcn_bn_bwd(const float* dout, const float* mask, const float* y1, const float* gamma1, const float* mean1,
-                const float* invstd1, const float* y2, const float* gamma2, const float* mean2, const float* invstd2,
+int agcn_bn_bwd(const float* dout, const void* mask, int mask_bits, const float* y1, const float* gamma1,
+                const float* mean1, const float* invstd1, const float* y2, const float* gamma2, const float* mean2, const float* invstd2,
                 float* part, float* coef, float* dy1, float* dgamma1, float* dbeta1, float* dy2, float* dgamma2,
                 float* dbeta2, int N, int C, int P, void* stream);
 

@@ -47,7 +47,7 @@ def test_argument_errors_are_reported_not_thrown():
     L = lib.load()
     # null pointers / bad sizes are rejected on the host before any launch (no GPU needed)
     assert L.agcn_conv_fwd(None, None, None, None, None, None, 0, 1, 1, 1, 1, 25, 9, 1, None) == -1
-    assert L.agcn_bn_act_fwd(None, None, None, None, None, None, None, 1, 1, 1, 0, 1, None) == -1
+    assert L.agcn_bn_act_fwd(None, None, None, None, None, None, None, None, 1, 1, 1, 0, 1, None) == -1
     assert L.agcn_adjacency_fwd(None, None, None, None, None, None, None, 1, 1, 1, 25, None) == -1
 
 

@@ -246,6 +246,16 @@ def test_bn_act_fwd_bwd(case):
     if mode == 2:
         assert rel(dy2, r.grad) < TOL
         assert rel(dg2, g2.grad) < TOL * 5 and rel(db2, b2.grad) < TOL * 5
+    # the sign bit mask of `out` (what the product path keeps for the backward) gives bit-identical results
+    out2, bits = ops.bn_act_fwd(y1g, st1, None if mode == 0 else rg, st2, relu=True, want_bits=True)
+    assert torch.equal(out2, out)
+    flat = (out.flatten() > 0)
+    words = bits.cpu().numpy().view(np.uint32)
+    unpacked = np.unpackbits(words.view(np.uint8), bitorder='little')[:flat.numel()].astype(bool)
+    assert np.array_equal(unpacked, flat.cpu().numpy())
+    res_b = ops.bn_bwd(f(dout), bits, y1g, f(g1), st1, rg if mode == 2 else None, f(g2) if mode == 2 else None, st2)
+    for a_, b_ in zip(res_b, (dy1, dg1, db1, dy2, dg2, db2)):
+        assert (a_ is None and b_ is None) or torch.equal(a_, b_)
 
 
 def test_sgd_step_matches_torch():
