@@ -20,6 +20,15 @@ __device__ __forceinline__ f32x16 mfma32(float a, float b, f32x16 c) {
 }
 __device__ __forceinline__ int mfma_row(int j, int h) { return (j & 3) + 8 * (j >> 2) + 4 * h; }
 
+// ReLU masks reach the kernels either as the fp32 activation tensor (positive = pass) or as its sign bit mask
+// (agcn_bn_act_fwd: bit e of word w <-> element 32*w + e); the raw 32-bit load of either kind and the test:
+__device__ __forceinline__ float mask_load(const float* m, long idx, int bits) {
+  return bits ? m[idx >> 5] : m[idx];            // bit-mask words are fetched as raw 32-bit patterns
+}
+__device__ __forceinline__ bool mask_pass(float raw, long idx, int bits) {
+  return bits ? ((__builtin_bit_cast(unsigned, raw) >> (idx & 31)) & 1u) != 0u : raw > 0.f;
+}
+
 // sum over the 32 lanes of a half-wave (lanes l and l^k stay inside the half for k<32)
 __device__ __forceinline__ float half_sum(float v) {
   v += __shfl_xor(v, 16);
@@ -63,7 +72,7 @@ int agcn_gcn_chain_tiles(int T);
 size_t agcn_gcn_chain_workspace(int M, int K, int T, int V);
 int agcn_gcn_chain(int mode, const float* in, const float* adj, const float* wcat, const float* bias, float* out,
                    float* stats_part, int accumulate, const float* add1, const float* mask1, const float* add2,
-                   const float* mask2, void* ws, size_t ws_bytes, int N, int C, int Cout, int T, int V,
+                   const float* mask2, int mask_bits, void* ws, size_t ws_bytes, int N, int C, int Cout, int T, int V,
                    hipStream_t stream);
 
 bool agcn_gcn_dadj_chain_supported(int C, int V);

@@ -42,6 +42,7 @@ struct ConvGemmArgs {
   int out_fs, out_fo, T_full;        // output frame = tau*out_fs + out_fo ; T_full = frames of the out tensor
   int FW, WLP;
   int accumulate;
+  int mask_bits;                     // mask1/mask2 are sign bit masks instead of fp32 tensors
   int C;                             // DADJ: channels of x
   int nchunks, nmb;
   int off_bx, off_bg, off_adj;       // LDS offsets (floats)
@@ -335,12 +336,12 @@ __global__ void __launch_bounds__(WM* WN * 64, (TAPS == 1 && EPI == 0 && (AGG ==
               if (a.accumulate) e += a.out[idx];
               if (a.add1) {
                 float t = a.add1[idx];
-                if (a.mask1) t = (a.mask1[idx] > 0.f) ? t : 0.f;
+                if (a.mask1) t = mask_pass(mask_load(a.mask1, idx, a.mask_bits), idx, a.mask_bits) ? t : 0.f;
                 e += t;
               }
               if (a.add2) {
                 float t = a.add2[idx];
-                if (a.mask2) t = (a.mask2[idx] > 0.f) ? t : 0.f;
+                if (a.mask2) t = mask_pass(mask_load(a.mask2, idx, a.mask_bits), idx, a.mask_bits) ? t : 0.f;
                 e += t;
               }
               ex[jj][tn] = e;
@@ -701,7 +702,7 @@ int agcn_gcn_aggregate_project_fwd(const float* x, const float* adj, const float
     return AGCN_ERR_ARG;
   // (the 3-channel first layer's forward stays on the f32 kernel: measured 193 us against 260 us chained)
   if (agcn_gemm_precision() == 3 && C >= 32 && agcn_gcn_chain_supported(Cout, C, V))
-    return agcn_gcn_chain(0, x, adj, wcat, bias, y, stats_part, 0, nullptr, nullptr, nullptr, nullptr, workspace,
+    return agcn_gcn_chain(0, x, adj, wcat, bias, y, stats_part, 0, nullptr, nullptr, nullptr, nullptr, 0, workspace,
                           workspace_bytes, N, C, Cout, T, V, (hipStream_t)stream);
   Problem p = {};
   ConvGemmArgs& a = p.a;
@@ -716,17 +717,17 @@ int agcn_gcn_aggregate_project_fwd(const float* x, const float* adj, const float
 // dx[n][c][t,u] (+)= sum_i sum_o wcat[o][i*C+c] * sum_v dy[n][o][t,v] adj[n][i][u][v]   (+ masked addends)
 int agcn_gcn_aggregate_project_bwd_data(const float* dy, const float* adj, const float* wcat, float* dx,
                                         int accumulate, const float* add1, const float* mask1, const float* add2,
-                                        const float* mask2, void* workspace, size_t workspace_bytes, int N, int C,
-                                        int Cout, int T, int V, void* stream) {
+                                        const float* mask2, int mask_bits, void* workspace, size_t workspace_bytes,
+                                        int N, int C, int Cout, int T, int V, void* stream) {
   if (!dy || !adj || !wcat || !dx || !workspace || N <= 0 || C <= 0 || Cout <= 0 || T <= 0 || V <= 0 || V > 32)
     return AGCN_ERR_ARG;
   if (agcn_gemm_precision() == 3 && agcn_gcn_chain_supported(C, Cout, V))
-    return agcn_gcn_chain(1, dy, adj, wcat, nullptr, dx, nullptr, accumulate, add1, mask1, add2, mask2, workspace,
-                          workspace_bytes, N, C, Cout, T, V, (hipStream_t)stream);
+    return agcn_gcn_chain(1, dy, adj, wcat, nullptr, dx, nullptr, accumulate, add1, mask1, add2, mask2, mask_bits,
+                          workspace, workspace_bytes, N, C, Cout, T, V, (hipStream_t)stream);
   Problem p = {};
   ConvGemmArgs& a = p.a;
   a.in = dy; a.out = dx; a.adj = adj; a.accumulate = accumulate;
-  a.add1 = add1; a.mask1 = mask1; a.add2 = add2; a.mask2 = mask2;
+  a.add1 = add1; a.mask1 = mask1; a.add2 = add2; a.mask2 = mask2; a.mask_bits = mask_bits;
   a.N = N; a.M = C; a.Kinner = Cout; a.in_rows = Cout; a.V = V; a.T_src = T; a.T_out = T; a.T_full = T;
   a.src_stride = 1; a.f_off = 0; a.out_fs = 1; a.out_fo = 0;
   p.w = wcat; p.sa_m = 1; p.sa_i = C; p.sa_c = 3L * C; p.tap_flip_from = -1;

@@ -39,6 +39,7 @@ struct ChainArgs {
   int ntiles, ncb, nmb;
   int accumulate;
   int adj_t;                   // 0: B[u][v] = adj[u][v] (forward); 1: B[u][v] = adj[v][u] (backward-data)
+  int mask_bits;               // mask1/mask2 are sign bit masks (agcn_bn_act_fwd) instead of fp32 tensors
   int XP;                      // pitch (floats) of an x chunk row in LDS (odd)
   int off_bias;                // byte offset of the bias row in LDS
 };
@@ -280,9 +281,9 @@ __global__ void __launch_bounds__(NW * 64, 2) gcn_chain_kernel(const ChainArgs a
         const long idx = base + ((q < xlen) ? q : 0);
         if (a.accumulate) e[0][g][u] = a.out[idx];
         if (a.add1) e[1][g][u] = a.add1[idx];
-        if (a.mask1) e[2][g][u] = a.mask1[idx];
+        if (a.mask1) e[2][g][u] = mask_load(a.mask1, idx, a.mask_bits);
         if (a.add2) e[3][g][u] = a.add2[idx];
-        if (a.mask2) e[4][g][u] = a.mask2[idx];
+        if (a.mask2) e[4][g][u] = mask_load(a.mask2, idx, a.mask_bits);
       }
     }
   };
@@ -337,8 +338,9 @@ __global__ void __launch_bounds__(NW * 64, 2) gcn_chain_kernel(const ChainArgs a
         const int q = lane + 64 * u;
         float v = tile[(r0 + g) * TP + min(q, TP - 1)] + bval;
         if (a.accumulate) v += ex[k & 1][0][g][u];
-        if (a.add1) v += (!a.mask1 || ex[k & 1][2][g][u] > 0.f) ? ex[k & 1][1][g][u] : 0.f;
-        if (a.add2) v += (!a.mask2 || ex[k & 1][4][g][u] > 0.f) ? ex[k & 1][3][g][u] : 0.f;
+        const long midx = base + ((q < xlen) ? q : 0);
+        if (a.add1) v += (!a.mask1 || mask_pass(ex[k & 1][2][g][u], midx, a.mask_bits)) ? ex[k & 1][1][g][u] : 0.f;
+        if (a.add2) v += (!a.mask2 || mask_pass(ex[k & 1][4][g][u], midx, a.mask_bits)) ? ex[k & 1][3][g][u] : 0.f;
         if (q < xlen) a.out[base + q] = v;
       }
     }
@@ -684,11 +686,11 @@ size_t agcn_gcn_chain_workspace(int M, int K, int T, int V) {   // pack size doe
 // mode 0: forward (in = x, K = C, M = Cout); mode 1: backward-data (in = dy, K = Cout, M = C)
 int agcn_gcn_chain(int mode, const float* in, const float* adj, const float* wcat, const float* bias, float* out,
                    float* stats_part, int accumulate, const float* add1, const float* mask1, const float* add2,
-                   const float* mask2, void* ws, size_t ws_bytes, int N, int C, int Cout, int T, int V,
+                   const float* mask2, int mask_bits, void* ws, size_t ws_bytes, int N, int C, int Cout, int T, int V,
                    hipStream_t stream) {
   ChainArgs a = {};
   a.in = in; a.adj = adj; a.bias = bias; a.out = out; a.stats = stats_part;
-  a.accumulate = accumulate; a.add1 = add1; a.mask1 = mask1; a.add2 = add2; a.mask2 = mask2;
+  a.accumulate = accumulate; a.add1 = add1; a.mask1 = mask1; a.add2 = add2; a.mask2 = mask2; a.mask_bits = mask_bits;
   a.N = N; a.T = T; a.V = V;
   long sa_m, sa_i, sa_c;
   if (mode == 0) { a.M = Cout; a.K = C; a.adj_t = 0; sa_m = 3L * C; sa_i = C; sa_c = 1; }

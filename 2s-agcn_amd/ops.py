@@ -124,13 +124,20 @@ def aggregate_project_fwd(x, adj, wcat, bias, want_stats=False):
 
 def aggregate_project_bwd_data(dy, adj, wcat, x_shape, out=None, accumulate=False, add1=None, mask1=None,
                                add2=None, mask2=None):
+    """dx (+)= sum_i Wd_i^T (dy . adj_i^T) + add1*[mask1] + add2*[mask2].  The masks are fp32 tensors (> 0 passes) or,
+    both of them, int32 sign bit masks (bn_act_fwd(..., want_bits=True))."""
     N, C, T, V = x_shape
     Cout = wcat.shape[0]
     dx = out if out is not None else _empty(x_shape, dy)
     ws, nb = _gcn_ws(C, Cout, T, V, dy)
+    kinds = {m.dtype for m in (mask1, mask2) if m is not None}
+    if len(kinds) > 1:
+        raise RuntimeError("agcn_amd: mask1 and mask2 must be of one kind (fp32 tensors or int32 sign bit masks)")
+    mbits = int(torch.int32 in kinds)
+    mp = _lib.ptr_bits if mbits else _lib.ptr
     _lib.check(_L().agcn_gcn_aggregate_project_bwd_data(
-        _lib.ptr(dy), _lib.ptr(adj), _lib.ptr(wcat), _lib.ptr(dx), int(accumulate), _lib.ptr(add1), _lib.ptr(mask1),
-        _lib.ptr(add2), _lib.ptr(mask2), ws.data_ptr(), nb, N, C, Cout, T, V, _lib.stream()),
+        _lib.ptr(dy), _lib.ptr(adj), _lib.ptr(wcat), _lib.ptr(dx), int(accumulate), _lib.ptr(add1), mp(mask1),
+        _lib.ptr(add2), mp(mask2), mbits, ws.data_ptr(), nb, N, C, Cout, T, V, _lib.stream()),
         "agcn_gcn_aggregate_project_bwd_data")
     return dx
 
@@ -339,7 +346,7 @@ def gcn_backward(c, dout, extra_add=None, extra_mask=None):
     dypre, dg1, db1, ddpre, dg2, db2 = bn_bwd(dout, c.g_bits, ypre, gamma1, c.g_bn1, dpre, gamma2, c.g_bn2)
     dwd = project_bwd_weight(dypre, x, adj, Cout)
     if dpre is None:      # identity `down`: dx += dout * (out > 0)
-        dx = aggregate_project_bwd_data(dypre, adj, wd, x.shape, add1=dout, mask1=out, add2=extra_add,
+        dx = aggregate_project_bwd_data(dypre, adj, wd, x.shape, add1=dout, mask1=c.g_bits, add2=extra_add,
                                         mask2=extra_mask)
     else:
         dx = aggregate_project_bwd_data(dypre, adj, wd, x.shape, add1=extra_add, mask1=extra_mask)
@@ -512,7 +519,7 @@ class TCNGCNUnitFunction(torch.autograd.Function):
         dout = dout.contiguous()
         dg, dtw, dtg, dtb, drpre, drw, drg, drb = tcn_backward(c, dout)
         if ctx.res_mode == 1:
-            gres = gcn_backward(c, dg, extra_add=dout, extra_mask=c.t_out)
+            gres = gcn_backward(c, dg, extra_add=dout, extra_mask=c.t_bits)
         else:
             gres = gcn_backward(c, dg)
         dx, dPA, dwab, dbab, dwd, dg1, db1, dwdown, dg2, db2 = gres

@@ -71,9 +71,10 @@ int agcn_gcn_stats_tiles(int C, int Cout, int T, int V);    /* stats_part slots 
 int agcn_gcn_aggregate_project_fwd(const float* x, const float* adj, const float* wcat, const float* bias, float* y,
                                    float* stats_part, void* workspace, size_t workspace_bytes, int N, int C, int Cout,
                                    int T, int V, void* stream);
+/* mask_bits = 1: mask1/mask2 are sign bit masks of agcn_bn_act_fwd (cast to const float*), 0: fp32 tensors (> 0 passes) */
 int agcn_gcn_aggregate_project_bwd_data(const float* dy, const float* adj, const float* wcat, float* dx,
                                         int accumulate, const float* add1, const float* mask1, const float* add2,
-                                        const float* mask2, void* workspace, size_t workspace_bytes, int N, int C,
+                                        const float* mask2, int mask_bits, void* workspace, size_t workspace_bytes, int N, int C,
                                         int Cout, int T, int V, void* stream);
 size_t agcn_gcn_project_bwd_weight_workspace(int N, int C, int Cout, int T, int V);
 int agcn_gcn_project_bwd_weight(const float* dy, const float* x, const float* adj, float* dwcat, void* workspace,

@@ -141,6 +141,15 @@ def test_aggregate_project(case):
     assert rel(dx2, ref2) < TOL
     dx3 = ops.aggregate_project_bwd_data(dyg, ag, wg, tuple(x.shape), add1=a1)
     assert rel(dx3, x.grad.float().to(dev) + a1) < TOL
+    # the same masks as sign bit masks (what the product path passes): bit-identical result
+
+    def pack(m):
+        b = np.packbits((m.flatten() > 0).cpu().numpy(), bitorder='little')
+        b = np.concatenate([b, np.zeros((-len(b)) % 4, np.uint8)])
+        return torch.from_numpy(b.view(np.int32).copy()).to(dev)
+    dx4 = ops.aggregate_project_bwd_data(dyg, ag, wg, tuple(x.shape), out=prior.clone(), accumulate=True, add1=a1,
+                                         mask1=pack(m1), add2=a2, mask2=pack(m2))
+    assert torch.equal(dx4, dx2)
     dw = ops.project_bwd_weight(dyg, xg, ag, Cout)
     assert rel(dw, wcat.grad) < TOL
     # adjacency gradient via the slot partials
