@@ -129,7 +129,37 @@ bn_bwd_reduce_kernel(const float* __restrict__ dout, const float* __restrict__ m
   const float* a = y1 + row * P;
   const float* b = HAS2 ? y2 + row * P : nullptr;
   float s0 = 0.f, s1 = 0.f, s2 = 0.f;
-  for (int q = threadIdx.x; q < P; q += 256) {
+  const int P4 = ((P & 3) == 0) ? (P >> 2) : 0;        // rows are 16-byte aligned when P is a multiple of 4: float4 path
+  for (int q4 = threadIdx.x; q4 < P4; q4 += 256) {
+    const float4 d4 = reinterpret_cast<const float4*>(d)[q4];
+    const float4 a4 = reinterpret_cast<const float4*>(a)[q4];
+    float dv[4] = {d4.x, d4.y, d4.z, d4.w};
+    const float av[4] = {a4.x, a4.y, a4.z, a4.w};
+    if (mk) {
+      const float4 m4 = reinterpret_cast<const float4*>(mk)[q4];
+      const float mv[4] = {m4.x, m4.y, m4.z, m4.w};
+#pragma unroll
+      for (int k = 0; k < 4; ++k) dv[k] = (mv[k] > 0.f) ? dv[k] : 0.f;
+    }
+    if (mb) {
+      const long e = e_row + 4L * q4;
+      const unsigned nib = mb[e >> 5] >> (e & 31);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) dv[k] = ((nib >> k) & 1u) ? dv[k] : 0.f;
+    }
+    float bv[4] = {0.f, 0.f, 0.f, 0.f};
+    if (HAS2) {
+      const float4 b4 = reinterpret_cast<const float4*>(b)[q4];
+      bv[0] = b4.x; bv[1] = b4.y; bv[2] = b4.z; bv[3] = b4.w;
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      s0 += dv[k];
+      s1 += dv[k] * av[k];
+      if (HAS2) s2 += dv[k] * bv[k];
+    }
+  }
+  for (int q = 4 * P4 + threadIdx.x; q < P; q += 256) {
     float dz = d[q];
     if (mk) dz = (mk[q] > 0.f) ? dz : 0.f;
     if (mb) {
