@@ -69,11 +69,11 @@ int agcn_bf16_conv1_bwd_data(const float* dy, const float* w, float* dx, int acc
 // register-chained aggregate+project (gcn_chain.hip); mode 0 = forward, 1 = backward-data
 bool agcn_gcn_chain_supported(int M, int K, int V);
 int agcn_gcn_chain_tiles(int T);
-size_t agcn_gcn_chain_workspace(int M, int K, int T, int V);
+size_t agcn_gcn_chain_workspace(int M, int K, int K2, int T, int V);
 int agcn_gcn_chain(int mode, const float* in, const float* adj, const float* wcat, const float* bias, float* out,
                    float* stats_part, int accumulate, const float* add1, const float* mask1, const float* add2,
-                   const float* mask2, int mask_bits, void* ws, size_t ws_bytes, int N, int C, int Cout, int T, int V,
-                   hipStream_t stream);
+                   const float* mask2, int mask_bits, const float* in2, const float* w2, int K2, void* ws, size_t ws_bytes,
+                   int N, int C, int Cout, int T, int V, hipStream_t stream);
 
 bool agcn_gcn_dadj_chain_supported(int C, int V);
 int agcn_gcn_dadj_chain_slots(int C, int T);

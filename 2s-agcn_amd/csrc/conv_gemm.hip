@@ -601,8 +601,9 @@ size_t agcn_gcn_workspace(int C, int Cout, int T, int V) {
   size_t b = PACK_BYTES_BM(1, 1, CKA, CKA, V, T, 1, Cout, C), t;
   t = PACK_BYTES_BM(1, 2, CKA, CKA, V, T, 1, C, Cout); if (t > b) b = t;
   t = pack_bytes<1, 0, 1, 4, 2, 1, CKD, 1>(V, T, 1, 3 * C, Cout); if (t > b) b = t;
-  if (agcn_gcn_chain_supported(Cout, C, V)) { t = agcn_gcn_chain_workspace(Cout, C, T, V); if (t > b) b = t; }
-  if (agcn_gcn_chain_supported(C, Cout, V)) { t = agcn_gcn_chain_workspace(C, Cout, T, V); if (t > b) b = t; }
+  if (agcn_gcn_chain_supported(Cout, C, V)) { t = agcn_gcn_chain_workspace(Cout, C, 0, T, V); if (t > b) b = t; }
+  // backward-data, with room for the fused theta/phi term (6*Cout/4 channels)
+  if (agcn_gcn_chain_supported(C, Cout, V)) { t = agcn_gcn_chain_workspace(C, Cout, 6 * (Cout / 4), T, V); if (t > b) b = t; }
   if (agcn_gcn_dadj_chain_supported(C, V)) { t = agcn_gcn_dadj_chain_workspace(C, Cout); if (t > b) b = t; }
   return b + 256;
 }
@@ -702,8 +703,8 @@ int agcn_gcn_aggregate_project_fwd(const float* x, const float* adj, const float
     return AGCN_ERR_ARG;
   // (the 3-channel first layer's forward stays on the f32 kernel: measured 193 us against 260 us chained)
   if (agcn_gemm_precision() == 3 && C >= 32 && agcn_gcn_chain_supported(Cout, C, V))
-    return agcn_gcn_chain(0, x, adj, wcat, bias, y, stats_part, 0, nullptr, nullptr, nullptr, nullptr, 0, workspace,
-                          workspace_bytes, N, C, Cout, T, V, (hipStream_t)stream);
+    return agcn_gcn_chain(0, x, adj, wcat, bias, y, stats_part, 0, nullptr, nullptr, nullptr, nullptr, 0, nullptr, nullptr,
+                          0, workspace, workspace_bytes, N, C, Cout, T, V, (hipStream_t)stream);
   Problem p = {};
   ConvGemmArgs& a = p.a;
   a.in = x; a.bias = bias; a.out = y; a.adj = adj; a.stats = stats_part;
@@ -723,7 +724,7 @@ int agcn_gcn_aggregate_project_bwd_data(const float* dy, const float* adj, const
     return AGCN_ERR_ARG;
   if (agcn_gemm_precision() == 3 && agcn_gcn_chain_supported(C, Cout, V))
     return agcn_gcn_chain(1, dy, adj, wcat, nullptr, dx, nullptr, accumulate, add1, mask1, add2, mask2, mask_bits,
-                          workspace, workspace_bytes, N, C, Cout, T, V, (hipStream_t)stream);
+                          nullptr, nullptr, 0, workspace, workspace_bytes, N, C, Cout, T, V, (hipStream_t)stream);
   Problem p = {};
   ConvGemmArgs& a = p.a;
   a.in = dy; a.out = dx; a.adj = adj; a.accumulate = accumulate;
@@ -733,6 +734,26 @@ int agcn_gcn_aggregate_project_bwd_data(const float* dy, const float* adj, const
   p.w = wcat; p.sa_m = 1; p.sa_i = C; p.sa_c = 3L * C; p.tap_flip_from = -1;
   p.ws = workspace; p.ws_bytes = workspace_bytes;
   return DISPATCH_BM(1, 2, CKA, CKA, 4, p, (hipStream_t)stream);
+}
+
+// Same, plus the 1x1 term of the adaptive branch in one pass:  dx (+)= ... + W2^T dtp  with dtp (N, K2, T, V) and
+// w2 (K2, C) row-major (the stacked conv_a/conv_b weights).  Only on the chained (bf16x6) path: check
+// agcn_gcn_bwd_data_fused_supported first.
+int agcn_gcn_bwd_data_fused_supported(int C, int Cout, int V) {
+  return agcn_gemm_precision() == 3 && agcn_gcn_chain_supported(C, Cout, V) ? 1 : 0;
+}
+int agcn_gcn_aggregate_project_bwd_data_fused(const float* dy, const float* adj, const float* wcat, const float* dtp,
+                                              const float* w2, int K2, float* dx, int accumulate, const float* add1,
+                                              const float* mask1, const float* add2, const float* mask2, int mask_bits,
+                                              void* workspace, size_t workspace_bytes, int N, int C, int Cout, int T,
+                                              int V, void* stream) {
+  if (!dy || !adj || !wcat || !dtp || !w2 || !dx || !workspace || N <= 0 || C <= 0 || Cout <= 0 || K2 <= 0 || T <= 0 ||
+      V <= 0 || V > 32)
+    return AGCN_ERR_ARG;
+  if (!agcn_gcn_bwd_data_fused_supported(C, Cout, V)) return AGCN_ERR_UNSUPPORTED;
+  if (agcn_gcn_chain_workspace(C, Cout, K2, T, V) > workspace_bytes) return AGCN_ERR_WORKSPACE;
+  return agcn_gcn_chain(1, dy, adj, wcat, nullptr, dx, nullptr, accumulate, add1, mask1, add2, mask2, mask_bits, dtp, w2,
+                        K2, workspace, workspace_bytes, N, C, Cout, T, V, (hipStream_t)stream);
 }
 
 // dadj_part[n][i][slot][u][v] = sum over the slot's (c,t) of x[n][c][t,u] * (sum_o wcat[o][i*C+c] dy[n][o][t,v])

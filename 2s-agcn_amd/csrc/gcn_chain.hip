@@ -40,6 +40,8 @@ struct ChainArgs {
   int accumulate;
   int adj_t;                   // 0: B[u][v] = adj[u][v] (forward); 1: B[u][v] = adj[v][u] (backward-data)
   int mask_bits;               // mask1/mask2 are sign bit masks (agcn_bn_act_fwd) instead of fp32 tensors
+  const float* in2;            // optional second, un-aggregated source (N, K2, T, V): acc += W2 . in2 (plain stages)
+  int K2, ncb2;                // its channels and 32-channel blocks (0: none)
   int XP;                      // pitch (floats) of an x chunk row in LDS (odd)
   int off_bias;                // byte offset of the bias row in LDS
 };
@@ -49,6 +51,7 @@ struct ChainPackArgs {
   unsigned short* wp;
   int M, K, ncb;
   long sa_m, sa_i, sa_c;       // W_i[m][c] = w[m*sa_m + i*sa_i + c*sa_c]
+  int nsub, s_total, s_off;    // subsets per channel block (3 / 1), stage images per row block, first stage written
 };
 
 __device__ __forceinline__ unsigned pack_bf16(float a, float b) {
@@ -76,10 +79,10 @@ template <int TM>
 __global__ void __launch_bounds__(256) chain_pack_kernel(const ChainPackArgs p) {
   constexpr int BM = TM * 32;
   constexpr int PER_PLANE = 2 * TM * 64 * 8;          // bf16 elements
-  const int i = blockIdx.x % 3;
-  const int cb = (blockIdx.x / 3) % p.ncb;
-  const int mb = blockIdx.x / (3 * p.ncb);
-  unsigned short* dst = p.wp + (long)blockIdx.x * 3 * PER_PLANE;
+  const int i = blockIdx.x % p.nsub;
+  const int cb = (blockIdx.x / p.nsub) % p.ncb;
+  const int mb = blockIdx.x / (p.nsub * p.ncb);
+  unsigned short* dst = p.wp + ((long)mb * p.s_total + p.s_off + (long)cb * p.nsub + i) * 3 * PER_PLANE;
   for (int e = threadIdx.x; e < PER_PLANE / 2; e += 256) {     // one bf16 pair per iteration
     const int e2 = e & 3;                 // slot pair (2*e2, 2*e2+1)
     const int lane = (e >> 2) & 63;
@@ -133,7 +136,9 @@ __global__ void __launch_bounds__(NW * 64, 2) gcn_chain_kernel(const ChainArgs a
   const bool fvalid = t < T;                           // wave-uniform
   const int xlen = min(FT, T - t0) * V;                // valid floats of a staged x row
   const long P = (long)T * V;
-  const int S = 3 * a.ncb;
+  const int S1 = 3 * a.ncb;                            // aggregated stages, then a.ncb2 plain stages
+  const int S = S1 + a.ncb2;
+  const int nchunks = a.ncb + a.ncb2;                  // staged source chunks: x blocks, then in2 blocks
 
   // bias of this row block, beyond everything the epilogue tile overwrites
   float* bias_s = reinterpret_cast<float*>(smem + a.off_bias);
@@ -172,11 +177,15 @@ __global__ void __launch_bounds__(NW * 64, 2) gcn_chain_kernel(const ChainArgs a
     for (int u = 0; u < EA; ++u)
       if (tid + u * NT < A16) dst[tid + u * NT] = ra[u];
   };
-  auto issue_X = [&](int cb) __attribute__((always_inline)) {
+  auto issue_X = [&](int chunk) __attribute__((always_inline)) {
+    const bool second = chunk >= a.ncb;
+    const float* srcT = second ? a.in2 : a.in;
+    const int KK = second ? a.K2 : a.K;
+    const int cb = second ? chunk - a.ncb : chunk;
 #pragma unroll
     for (int j = 0; j < XR; ++j) {
       const int c = cb * CB + wave * XR + j;
-      const float* rowp = a.in + ((long)n * a.K + min(c, a.K - 1)) * P + (long)t0 * V;
+      const float* rowp = srcT + ((long)n * KK + min(c, KK - 1)) * P + (long)t0 * V;
 #pragma unroll
       for (int u = 0; u < XB; ++u) {
         const int q = lane + 64 * u;
@@ -184,11 +193,14 @@ __global__ void __launch_bounds__(NW * 64, 2) gcn_chain_kernel(const ChainArgs a
       }
     }
   };
-  auto commit_X = [&](int cb) __attribute__((always_inline)) {
+  auto commit_X = [&](int chunk) __attribute__((always_inline)) {
+    const bool second = chunk >= a.ncb;
+    const int KK = second ? a.K2 : a.K;
+    const int cb = second ? chunk - a.ncb : chunk;
 #pragma unroll
     for (int j = 0; j < XR; ++j) {
       const int cl = wave * XR + j;
-      const bool rok = (cb * CB + cl) < a.K;
+      const bool rok = (cb * CB + cl) < KK;
 #pragma unroll
       for (int u = 0; u < XB; ++u) {
         const int q = lane + 64 * u;
@@ -207,27 +219,45 @@ __global__ void __launch_bounds__(NW * 64, 2) gcn_chain_kernel(const ChainArgs a
 
   float xo[VS];
   for (int s = 0; s < S; ++s) {
-    const int cb = s / 3, i = s - cb * 3;
-    if (s + 1 < S) commit_A(s + 1);                    // loads were issued one stage ago
-    if (i == 2 && cb + 1 < a.ncb) commit_X(cb + 1);    // xb is free: every wave took its operands at i == 0
-    if (s + 2 < S) issue_A(s + 2);
-    if (i == 0 && cb + 1 < a.ncb) issue_X(cb + 1);
+    const bool plain = s >= S1;
+    const int cb = plain ? 0 : s / 3, i = plain ? 0 : s - cb * 3;
+    f32x16 d;
+    if (plain) {
+      // Plain stage: the B operand is the staged chunk itself (register j of lane (h, v) = channel c_j + 4h), no
+      // aggregation.  Every wave takes its 16 values first; only then may the next chunk overwrite the buffer.
+      const int chunk = a.ncb + (s - S1);
+      const float* xr = xb + wave * V + min(lr, V - 1);
+#pragma unroll
+      for (int j = 0; j < 16; ++j) d[j] = xr[((j & 3) + 8 * (j >> 2) + 4 * h) * XP];
+      __syncthreads();
+      if (chunk + 1 < nchunks) commit_X(chunk + 1);
+      if (s + 1 < S) commit_A(s + 1);
+      if (s + 2 < S) issue_A(s + 2);
+      if (chunk + 2 < nchunks) issue_X(chunk + 2);
+    } else {
+      if (s + 1 < S) commit_A(s + 1);                    // loads were issued one stage ago
+      if (i == 2 && cb + 1 < nchunks) commit_X(cb + 1);  // xb is free: every wave took its operands at i == 0
+      if (s + 2 < S) issue_A(s + 2);
+      if (i == 0 && cb + 1 < nchunks) issue_X(cb + 1);
+      if (i == 2 && cb + 1 == a.ncb && cb + 2 < nchunks) issue_X(cb + 2);   // second plain chunk: one stage ahead
+    }
     if (fvalid) {
-      // ---- 1. G = X[cb] . A^_i for this wave's frame ----
-      const float* xr = xb + lr * XP + wave * V;
-      const float* ar = adjp + i * 1024 + lr;
-      f32x16 d;
+      if (!plain) {
+        // ---- 1. G = X[cb] . A^_i for this wave's frame ----
+        const float* xr = xb + lr * XP + wave * V;
+        const float* ar = adjp + i * 1024 + lr;
 #pragma unroll
-      for (int j = 0; j < 16; ++j) d[j] = 0.f;
-      if (i == 0) {
+        for (int j = 0; j < 16; ++j) d[j] = 0.f;
+        if (i == 0) {
 #pragma unroll
-        for (int k = 0; k < VS; ++k) xo[k] = xr[min(2 * k + h, V - 1)];
+          for (int k = 0; k < VS; ++k) xo[k] = xr[min(2 * k + h, V - 1)];
+        }
+        float bo[VS];
+#pragma unroll
+        for (int k = 0; k < VS; ++k) bo[k] = ar[(2 * k + h) * 32];
+#pragma unroll
+        for (int k = 0; k < VS; ++k) d = mfma32(xo[k], bo[k], d);
       }
-      float bo[VS];
-#pragma unroll
-      for (int k = 0; k < VS; ++k) bo[k] = ar[(2 * k + h) * 32];
-#pragma unroll
-      for (int k = 0; k < VS; ++k) d = mfma32(xo[k], bo[k], d);
       // ---- 2. split G in registers and project: acc[tm] += W_i[:, cb] . G ----
       const unsigned char* ab = abuf + (s & 1) * A_IMG + lane * 16;
 #pragma unroll
@@ -372,20 +402,38 @@ ChainGeom chain_geometry(int V, int T, int M, int K) {
   return g;
 }
 
+struct ChainW2 {
+  const float* w;
+  long sa_m, sa_c;      // W2[m][k] = w[m*sa_m + k*sa_c]
+};
+
 template <int TM, int VS, int NW>
-int chain_launch(ChainArgs a, const float* w, long sa_m, long sa_i, long sa_c, void* ws, size_t ws_bytes,
-                 hipStream_t stream) {
+int chain_launch(ChainArgs a, const float* w, long sa_m, long sa_i, long sa_c, const ChainW2& g_w2, void* ws,
+                 size_t ws_bytes, hipStream_t stream) {
   const ChainGeom g = chain_geometry<TM, NW>(a.V, a.T, a.M, a.K);
   if (g.smem_bytes > 160 * 1024) return AGCN_ERR_UNSUPPORTED;
-  if (g.pack_bytes > ws_bytes) return AGCN_ERR_WORKSPACE;
+  a.ncb2 = a.in2 ? (a.K2 + CB - 1) / CB : 0;
+  const int s_total = 3 * g.ncb + a.ncb2;
+  const size_t a_img = (size_t)3 * 2 * TM * 1024;
+  if ((size_t)g.nmb * s_total * a_img > ws_bytes) return AGCN_ERR_WORKSPACE;
   a.ntiles = g.ntiles; a.ncb = g.ncb; a.nmb = g.nmb; a.XP = g.XP; a.off_bias = g.off_bias;
   a.wp = (const unsigned short*)ws;
   ChainPackArgs pk;
   pk.w = w; pk.wp = (unsigned short*)ws; pk.M = a.M; pk.K = a.K; pk.ncb = g.ncb;
   pk.sa_m = sa_m; pk.sa_i = sa_i; pk.sa_c = sa_c;
+  pk.nsub = 3; pk.s_total = s_total; pk.s_off = 0;
   hipLaunchKernelGGL((chain_pack_kernel<TM>), dim3(g.nmb * g.ncb * 3), dim3(256), 0, stream, pk);
   int rc = agcn_check_launch();
   if (rc) return rc;
+  if (a.ncb2 > 0) {        // images of the plain stages, after the aggregated ones of each row block
+    ChainPackArgs p2;
+    p2.w = g_w2.w; p2.wp = (unsigned short*)ws; p2.M = a.M; p2.K = a.K2; p2.ncb = a.ncb2;
+    p2.sa_m = g_w2.sa_m; p2.sa_i = 0; p2.sa_c = g_w2.sa_c;
+    p2.nsub = 1; p2.s_total = s_total; p2.s_off = 3 * g.ncb;
+    hipLaunchKernelGGL((chain_pack_kernel<TM>), dim3(g.nmb * a.ncb2), dim3(256), 0, stream, p2);
+    rc = agcn_check_launch();
+    if (rc) return rc;
+  }
   auto kern = gcn_chain_kernel<TM, VS, NW>;
   static bool attr_set = false;
   if (!attr_set) {
@@ -399,12 +447,12 @@ int chain_launch(ChainArgs a, const float* w, long sa_m, long sa_i, long sa_c, v
 }
 
 template <int TM, int NW>
-int chain_dispatch_vs(const ChainArgs& a, const float* w, long sa_m, long sa_i, long sa_c, void* ws, size_t ws_bytes,
-                      hipStream_t stream) {
+int chain_dispatch_vs(const ChainArgs& a, const float* w, long sa_m, long sa_i, long sa_c, const ChainW2& w2, void* ws,
+                      size_t ws_bytes, hipStream_t stream) {
   const int vs = (a.V + 1) / 2;
-  if (vs == 13) return chain_launch<TM, 13, NW>(a, w, sa_m, sa_i, sa_c, ws, ws_bytes, stream);
-  if (vs == 9) return chain_launch<TM, 9, NW>(a, w, sa_m, sa_i, sa_c, ws, ws_bytes, stream);
-  return chain_launch<TM, 16, NW>(a, w, sa_m, sa_i, sa_c, ws, ws_bytes, stream);
+  if (vs == 13) return chain_launch<TM, 13, NW>(a, w, sa_m, sa_i, sa_c, w2, ws, ws_bytes, stream);
+  if (vs == 9) return chain_launch<TM, 9, NW>(a, w, sa_m, sa_i, sa_c, w2, ws, ws_bytes, stream);
+  return chain_launch<TM, 16, NW>(a, w, sa_m, sa_i, sa_c, w2, ws, ws_bytes, stream);
 }
 
 
@@ -677,31 +725,39 @@ bool agcn_gcn_chain_supported(int M, int K, int V) { return M >= 1 && K >= 1 && 
 
 int agcn_gcn_chain_tiles(int T) { return (T + chain_waves() - 1) / chain_waves(); }
 
-size_t agcn_gcn_chain_workspace(int M, int K, int T, int V) {   // pack size does not depend on the frame tile
-  const int tm = chain_tm(M);
-  return tm == 4 ? chain_geometry<4, 8>(V, T, M, K).pack_bytes
-                 : (tm == 2 ? chain_geometry<2, 8>(V, T, M, K).pack_bytes : chain_geometry<1, 8>(V, T, M, K).pack_bytes);
+// packed weight images; K2 = channels of the optional plain second source (0: none)
+size_t agcn_gcn_chain_workspace(int M, int K, int K2, int T, int V) {
+  (void)T; (void)V;
+  const int tm = chain_tm(M), bm = 32 * tm;
+  const size_t a_img = (size_t)3 * 2 * tm * 1024;
+  return (size_t)((M + bm - 1) / bm) * (3 * ((K + CB - 1) / CB) + (K2 + CB - 1) / CB) * a_img;
 }
 
 // mode 0: forward (in = x, K = C, M = Cout); mode 1: backward-data (in = dy, K = Cout, M = C)
 int agcn_gcn_chain(int mode, const float* in, const float* adj, const float* wcat, const float* bias, float* out,
                    float* stats_part, int accumulate, const float* add1, const float* mask1, const float* add2,
-                   const float* mask2, int mask_bits, void* ws, size_t ws_bytes, int N, int C, int Cout, int T, int V,
-                   hipStream_t stream) {
+                   const float* mask2, int mask_bits, const float* in2, const float* w2, int K2, void* ws, size_t ws_bytes,
+                   int N, int C, int Cout, int T, int V, hipStream_t stream) {
   ChainArgs a = {};
+  // optional fused 1x1 term (backward-data only): out += W2^T . in2 with w2 (K2, M) row-major, e.g. the theta/phi
+  // branch  dx += Wab^T dtp  (reference agcn.py:99-100 differentiated)
+  a.in2 = (in2 && w2 && K2 > 0) ? in2 : nullptr;
+  a.K2 = a.in2 ? K2 : 0;
+  ChainW2 cw2 = {w2, 1, 0};
   a.in = in; a.adj = adj; a.bias = bias; a.out = out; a.stats = stats_part;
   a.accumulate = accumulate; a.add1 = add1; a.mask1 = mask1; a.add2 = add2; a.mask2 = mask2; a.mask_bits = mask_bits;
   a.N = N; a.T = T; a.V = V;
   long sa_m, sa_i, sa_c;
   if (mode == 0) { a.M = Cout; a.K = C; a.adj_t = 0; sa_m = 3L * C; sa_i = C; sa_c = 1; }
   else           { a.M = C; a.K = Cout; a.adj_t = 1; sa_m = 1; sa_i = C; sa_c = 3L * C; }
+  cw2.sa_c = a.M;        // W2[m][k] = w2[k*M + m]
   if (chain_waves() == 8 && chain_tm(a.M) != 1) {
-    if (chain_tm(a.M) == 4) return chain_dispatch_vs<4, 8>(a, wcat, sa_m, sa_i, sa_c, ws, ws_bytes, stream);
-    return chain_dispatch_vs<2, 8>(a, wcat, sa_m, sa_i, sa_c, ws, ws_bytes, stream);
+    if (chain_tm(a.M) == 4) return chain_dispatch_vs<4, 8>(a, wcat, sa_m, sa_i, sa_c, cw2, ws, ws_bytes, stream);
+    return chain_dispatch_vs<2, 8>(a, wcat, sa_m, sa_i, sa_c, cw2, ws, ws_bytes, stream);
   }
-  if (chain_tm(a.M) == 4) return chain_dispatch_vs<4, 4>(a, wcat, sa_m, sa_i, sa_c, ws, ws_bytes, stream);
-  if (chain_tm(a.M) == 1) return chain_dispatch_vs<1, 4>(a, wcat, sa_m, sa_i, sa_c, ws, ws_bytes, stream);
-  return chain_dispatch_vs<2, 4>(a, wcat, sa_m, sa_i, sa_c, ws, ws_bytes, stream);
+  if (chain_tm(a.M) == 4) return chain_dispatch_vs<4, 4>(a, wcat, sa_m, sa_i, sa_c, cw2, ws, ws_bytes, stream);
+  if (chain_tm(a.M) == 1) return chain_dispatch_vs<1, 4>(a, wcat, sa_m, sa_i, sa_c, cw2, ws, ws_bytes, stream);
+  return chain_dispatch_vs<2, 4>(a, wcat, sa_m, sa_i, sa_c, cw2, ws, ws_bytes, stream);
 }
 
 // ---- adjacency gradient (gcn_dadj_chain_kernel): C a multiple of 64; row block 128 when C is a multiple of 128 ----

@@ -123,9 +123,10 @@ def aggregate_project_fwd(x, adj, wcat, bias, want_stats=False):
 
 
 def aggregate_project_bwd_data(dy, adj, wcat, x_shape, out=None, accumulate=False, add1=None, mask1=None,
-                               add2=None, mask2=None):
-    """dx (+)= sum_i Wd_i^T (dy . adj_i^T) + add1*[mask1] + add2*[mask2].  The masks are fp32 tensors (> 0 passes) or,
-    both of them, int32 sign bit masks (bn_act_fwd(..., want_bits=True))."""
+                               add2=None, mask2=None, dtp=None, wab=None):
+    """dx (+)= sum_i Wd_i^T (dy . adj_i^T) + add1*[mask1] + add2*[mask2] [+ wab^T dtp].  The masks are fp32 tensors
+    (> 0 passes) or, both of them, int32 sign bit masks (bn_act_fwd(..., want_bits=True)).  dtp/wab: the 1x1 term of
+    the adaptive branch fused into the same pass (only where fused_bwd_data_supported says so)."""
     N, C, T, V = x_shape
     Cout = wcat.shape[0]
     dx = out if out is not None else _empty(x_shape, dy)
@@ -135,11 +136,22 @@ def aggregate_project_bwd_data(dy, adj, wcat, x_shape, out=None, accumulate=Fals
         raise RuntimeError("agcn_amd: mask1 and mask2 must be of one kind (fp32 tensors or int32 sign bit masks)")
     mbits = int(torch.int32 in kinds)
     mp = _lib.ptr_bits if mbits else _lib.ptr
+    if dtp is not None:
+        K2 = dtp.shape[1]
+        _lib.check(_L().agcn_gcn_aggregate_project_bwd_data_fused(
+            _lib.ptr(dy), _lib.ptr(adj), _lib.ptr(wcat), _lib.ptr(dtp), _lib.ptr(wab.reshape(K2, C)), K2, _lib.ptr(dx),
+            int(accumulate), _lib.ptr(add1), mp(mask1), _lib.ptr(add2), mp(mask2), mbits, ws.data_ptr(), nb, N, C, Cout,
+            T, V, _lib.stream()), "agcn_gcn_aggregate_project_bwd_data_fused")
+        return dx
     _lib.check(_L().agcn_gcn_aggregate_project_bwd_data(
         _lib.ptr(dy), _lib.ptr(adj), _lib.ptr(wcat), _lib.ptr(dx), int(accumulate), _lib.ptr(add1), mp(mask1),
         _lib.ptr(add2), mp(mask2), mbits, ws.data_ptr(), nb, N, C, Cout, T, V, _lib.stream()),
         "agcn_gcn_aggregate_project_bwd_data")
     return dx
+
+
+def fused_bwd_data_supported(C, Cout, V):
+    return bool(_L().agcn_gcn_bwd_data_fused_supported(int(C), int(Cout), int(V)))
 
 
 def project_bwd_weight(dy, x, adj, Cout):
@@ -345,15 +357,18 @@ def gcn_backward(c, dout, extra_add=None, extra_mask=None):
     Cout = wd.shape[0]
     dypre, dg1, db1, ddpre, dg2, db2 = bn_bwd(dout, c.g_bits, ypre, gamma1, c.g_bn1, dpre, gamma2, c.g_bn2)
     dwd = project_bwd_weight(dypre, x, adj, Cout)
-    if dpre is None:      # identity `down`: dx += dout * (out > 0)
-        dx = aggregate_project_bwd_data(dypre, adj, wd, x.shape, add1=dout, mask1=c.g_bits, add2=extra_add,
-                                        mask2=extra_mask)
-    else:
-        dx = aggregate_project_bwd_data(dypre, adj, wd, x.shape, add1=extra_add, mask1=extra_mask)
-    dPA = dwab = dbab = dalpha = None
-    if c.g_adaptive:
+    dPA = dwab = dbab = dalpha = dtp = None
+    if c.g_adaptive:      # adjacency branch first: its dtp rides along in the dx kernel where that is supported
         dPA, dtp, dbab, dalpha, _ = adjacency_bwd(dypre, wd, x, tp, P, c.g_alpha)
         dwab = conv_bwd_weight(dtp, x, wab.shape)
+    fuse = dtp is not None and fused_bwd_data_supported(x.shape[1], Cout, x.shape[3])
+    ftp = dict(dtp=dtp, wab=wab) if fuse else {}
+    if dpre is None:      # identity `down`: dx += dout * (out > 0)
+        dx = aggregate_project_bwd_data(dypre, adj, wd, x.shape, add1=dout, mask1=c.g_bits, add2=extra_add,
+                                        mask2=extra_mask, **ftp)
+    else:
+        dx = aggregate_project_bwd_data(dypre, adj, wd, x.shape, add1=extra_add, mask1=extra_mask, **ftp)
+    if dtp is not None and not fuse:
         conv_bwd_data(dtp, wab, x.shape, out=dx, accumulate=True)
     c.g_dalpha = dalpha
     dwdown = None

@@ -76,6 +76,15 @@ int agcn_gcn_aggregate_project_bwd_data(const float* dy, const float* adj, const
                                         int accumulate, const float* add1, const float* mask1, const float* add2,
                                         const float* mask2, int mask_bits, void* workspace, size_t workspace_bytes, int N, int C,
                                         int Cout, int T, int V, void* stream);
+/* the same plus the 1x1 term of the adaptive branch in one pass: dx (+)= ... + w2^T dtp, dtp (N, K2, T, V), w2 (K2, C)
+ * row-major = the stacked conv_a/conv_b weights (reference agcn.py:99-100 differentiated).  Chained (bf16x6) path only:
+ * agcn_gcn_bwd_data_fused_supported() tells; workspace as agcn_gcn_workspace(C, Cout, T, V). */
+int agcn_gcn_bwd_data_fused_supported(int C, int Cout, int V);
+int agcn_gcn_aggregate_project_bwd_data_fused(const float* dy, const float* adj, const float* wcat, const float* dtp,
+                                              const float* w2, int K2, float* dx, int accumulate, const float* add1,
+                                              const float* mask1, const float* add2, const float* mask2, int mask_bits,
+                                              void* workspace, size_t workspace_bytes, int N, int C, int Cout, int T,
+                                              int V, void* stream);
 size_t agcn_gcn_project_bwd_weight_workspace(int N, int C, int Cout, int T, int V);
 int agcn_gcn_project_bwd_weight(const float* dy, const float* x, const float* adj, float* dwcat, void* workspace,
                                 size_t workspace_bytes, int N, int C, int Cout, int T, int V, void* stream);

@@ -150,6 +150,15 @@ def test_aggregate_project(case):
     dx4 = ops.aggregate_project_bwd_data(dyg, ag, wg, tuple(x.shape), out=prior.clone(), accumulate=True, add1=a1,
                                          mask1=pack(m1), add2=a2, mask2=pack(m2))
     assert torch.equal(dx4, dx2)
+    # the adaptive branch's 1x1 term fused into the same pass: dx += wab^T dtp
+    if ops.fused_bwd_data_supported(C, Cout, V):
+        K2 = 6 * (Cout // 4)
+        dtp = rnd(g, N, K2, T, V)
+        wab = rnd(g, K2, C, scale=1.0 / np.sqrt(K2))
+        ref5 = x.grad + torch.einsum('kc,nktv->nctv', wab, dtp)
+        dx5 = ops.aggregate_project_bwd_data(dyg, ag, wg, tuple(x.shape), dtp=dtp.float().to(dev),
+                                             wab=wab.float().to(dev).view(K2, C, 1, 1))
+        assert rel(dx5, ref5) < TOL
     dw = ops.project_bwd_weight(dyg, xg, ag, Cout)
     assert rel(dw, wcat.grad) < TOL
     # adjacency gradient via the slot partials
