@@ -355,6 +355,16 @@ inline int sc_tile_frames(int V, int T) {
 
 }  // namespace
 
+// sum the (sample, subset, tile) score slabs, scale by 1/(Ci*T), column softmax, add the static graph terms
+// (shared with adj_fused.hip)
+int agcn_adj_finalize(const float* spart, const float* A, const float* PA, const float* alpha, float* P, float* adj,
+                      int N, int Ci, int T, int V, hipStream_t s) {
+  const int tt = sc_tile_frames(V, T), ntiles = (T + tt - 1) / tt;
+  hipLaunchKernelGGL(adj_finalize_kernel, dim3(N * 3), dim3(256), 0, s, spart, A, PA, alpha, P, adj, V, ntiles,
+                     1.0f / ((float)Ci * (float)T));
+  return agcn_check_launch();
+}
+
 extern "C" {
 
 int agcn_scores_num_tiles(int V, int T) {
@@ -372,9 +382,7 @@ int agcn_adjacency_fwd(const float* tp, const float* A, const float* PA, const f
   hipLaunchKernelGGL(scores_fwd_kernel, dim3(N * ntiles, 3), dim3(256), smem, s, tp, spart, N, Ci, T, V, tt, ntiles);
   int rc = agcn_check_launch();
   if (rc) return rc;
-  hipLaunchKernelGGL(adj_finalize_kernel, dim3(N * 3), dim3(256), 0, s, (const float*)spart, A, PA, alpha, P, adj, V,
-                     ntiles, 1.0f / ((float)Ci * (float)T));
-  return agcn_check_launch();
+  return agcn_adj_finalize(spart, A, PA, alpha, P, adj, N, Ci, T, V, s);
 }
 
 // dadj_part: (N,3,nslots,V,V) from agcn_gcn_dadj ; outputs: dadj (N,3,V,V) scratch, dS (N,3,V,V), dPA (3,V,V),

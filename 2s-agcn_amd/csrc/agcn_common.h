@@ -50,6 +50,10 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
 extern "C" size_t agcn_colsum_scratch_bytes(int W);
 extern "C" int agcn_colsum(const float* X, int nslots, int W, void* scratch, float* out, void* stream);
 
+// adjacency.hip: slab sum + 1/K + column softmax + graph terms (also the tail of adj_fused.hip's forward)
+int agcn_adj_finalize(const float* spart, const float* A, const float* PA, const float* alpha, float* P, float* adj,
+                      int N, int Ci, int T, int V, hipStream_t s);
+
 // split-bf16 temporal convolution (conv_gemm_bf16.hip); npl: 3 = bf16x6 (fp32-equivalent), 2 = bf16x3
 size_t agcn_bf16_conv_workspace(int Cin, int Cout, int T, int V, int stride);
 bool agcn_bf16_conv_wide(int taps, int M);
@@ -99,6 +103,20 @@ static inline int agcn_gemm_precision() {
     else if (e && !strcmp(e, "bf16x3")) mode = 2;
   }
   return mode;
+}
+
+// Raise a kernel's dynamic-LDS limit to 160 KB on the CURRENT device, once per (kernel, device).  hipFuncSetAttribute
+// is per device, and forward / autograd-backward threads may reach a first launch together: the flags are atomics and
+// a lost race only repeats the idempotent call.  `done` is a static array owned by the launcher instantiation.
+#define AGCN_MAX_DEVICES 64
+static inline int agcn_allow_big_lds_rt(const void* kern, unsigned char* done) {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= AGCN_MAX_DEVICES) dev = -1;
+  if (dev >= 0 && __atomic_load_n(&done[dev], __ATOMIC_ACQUIRE)) return AGCN_OK;
+  hipError_t e = hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  if (e != hipSuccess) return (int)e;
+  if (dev >= 0) __atomic_store_n(&done[dev], (unsigned char)1, __ATOMIC_RELEASE);
+  return AGCN_OK;
 }
 
 static inline int agcn_check_launch() {

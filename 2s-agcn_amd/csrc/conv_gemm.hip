@@ -519,13 +519,8 @@ int launch_cfg(Problem& p, hipStream_t stream) {
     if (rc) return rc;
   }
   auto kern = conv_gemm_kernel<TAPS, AGG, WM, WN, TM, TN, CK, WB, EPI>;
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    if (e != hipSuccess) return (int)e;
-    attr_set = true;
-  }
+  static unsigned char lds_ok[AGCN_MAX_DEVICES] = {};   // per (kernel instantiation, device): the attribute is per device
+  if (int e = agcn_allow_big_lds_rt(reinterpret_cast<const void*>(kern), lds_ok)) return e;
   dim3 grid((unsigned)(a.N * g.ntiles * g.nmb));
   hipLaunchKernelGGL(kern, grid, dim3(WM * WN * 64), g.smem_bytes, stream, a);
   return agcn_check_launch();

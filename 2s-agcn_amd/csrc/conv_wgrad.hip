@@ -352,13 +352,8 @@ int launch_wgrad(WgradArgs a, float* dw, void* ws, size_t ws_bytes, hipStream_t 
   a.nsplit = g.nsplit; a.pairs_per_split = g.pairs_per_split;
   a.off_bx = g.off_bx; a.off_bg = g.off_bg; a.off_adj = g.off_adj; a.off_qoff = g.off_qoff;
   auto kern = conv_wgrad_kernel<TAPS, AGG, MW, CW, TH, KSPLIT, WBX>;
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    if (e != hipSuccess) return (int)e;
-    attr_set = true;
-  }
+  static unsigned char lds_ok[AGCN_MAX_DEVICES] = {};   // per (kernel instantiation, device): the attribute is per device
+  if (int e = agcn_allow_big_lds_rt(reinterpret_cast<const void*>(kern), lds_ok)) return e;
   hipLaunchKernelGGL(kern, dim3(g.grid_x, g.nsplit), dim3(512), g.smem_bytes, stream, a);
   int rc = agcn_check_launch();
   if (rc) return rc;

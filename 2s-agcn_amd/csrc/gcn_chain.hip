@@ -435,13 +435,8 @@ int chain_launch(ChainArgs a, const float* w, long sa_m, long sa_i, long sa_c, c
     if (rc) return rc;
   }
   auto kern = gcn_chain_kernel<TM, VS, NW>;
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    if (e != hipSuccess) return (int)e;
-    attr_set = true;
-  }
+  static unsigned char lds_ok[AGCN_MAX_DEVICES] = {};   // per (kernel instantiation, device): the attribute is per device
+  if (int e = agcn_allow_big_lds_rt(reinterpret_cast<const void*>(kern), lds_ok)) return e;
   hipLaunchKernelGGL(kern, dim3((unsigned)(a.N * g.ntiles * g.nmb)), dim3(NW * 64), g.smem_bytes, stream, a);
   return agcn_check_launch();
 }
@@ -695,13 +690,8 @@ int dadj_chain_launch(DadjArgs a, const float* wcat, void* ws, size_t ws_bytes, 
   int rc = agcn_check_launch();
   if (rc) return rc;
   auto kern = gcn_dadj_chain_kernel<TM, NW>;
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    if (e != hipSuccess) return (int)e;
-    attr_set = true;
-  }
+  static unsigned char lds_ok[AGCN_MAX_DEVICES] = {};   // per (kernel instantiation, device): the attribute is per device
+  if (int e = agcn_allow_big_lds_rt(reinterpret_cast<const void*>(kern), lds_ok)) return e;
   hipLaunchKernelGGL(kern, dim3((unsigned)(a.N * a.ntiles * a.nmb)), dim3(NW * 64), smem_bytes, stream, a);
   return agcn_check_launch();
 }

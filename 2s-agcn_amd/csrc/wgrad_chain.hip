@@ -276,13 +276,8 @@ int wc_launch(WcArgs a, void* ws, size_t ws_bytes, int* nslabs_out, hipStream_t 
   a.part = (float*)ws;
   a.ntiles = g.ntiles; a.pairs_per_split = g.pairs_per_split; a.ncg = g.ncg; a.XP = g.XP;
   auto kern = wgrad_chain_kernel<AGG, TM, NCB, VS, NW>;
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    if (e != hipSuccess) return (int)e;
-    attr_set = true;
-  }
+  static unsigned char lds_ok[AGCN_MAX_DEVICES] = {};   // per (kernel instantiation, device): the attribute is per device
+  if (int e = agcn_allow_big_lds_rt(reinterpret_cast<const void*>(kern), lds_ok)) return e;
   hipLaunchKernelGGL(kern, dim3(g.grid_x, g.nsplit), dim3(NW * 64), g.smem_bytes, stream, a);
   *nslabs_out = g.nslabs;
   return agcn_check_launch();

@@ -31,21 +31,24 @@ def init_distributed(backend=None, device=None):
 
 
 def enable_sync_bn(model, world_size, group=None):
-    """Reference DDP semantics (utils/processor.py:295 converts every BatchNorm to SyncBatchNorm): the HIP layers
-    all-reduce their per-channel sums (ops.set_sync_bn) and the stock ``data_bn`` is converted by torch.
+    """Reference DDP semantics (utils/processor.py:295 converts every BatchNorm to SyncBatchNorm): the model's
+    BatchNorm modules are converted by torch exactly as the reference does; the HIP units see the converted class of
+    the module whose parameters they borrow (``ops.sync_of``) and all-reduce their per-channel sums over its process
+    group, the stock ``data_bn`` runs torch's SyncBatchNorm.  The policy lives on the modules: nothing process-global.
     Returns the (possibly converted) model.  With world_size 1 nothing changes."""
-    from . import ops
-    ops.set_sync_bn(world_size, group)
     if world_size > 1:
         model = torch.nn.SyncBatchNorm.convert_sync_batchnorm(model, process_group=group)
     return model
 
 
-def allreduce_gradients(flat_grad, world_size):
-    """SUM all-reduce of the flat gradient buffer (one collective per step).  The caller applies 1/world_size."""
+def allreduce_gradients(flat_grad, world_size, async_op=False):
+    """SUM all-reduce of (a slice of) the flat gradient buffer.  The caller applies 1/world_size.
+    async_op: returns the work handle (None for world_size 1); with RCCL the collective runs on the communicator's own
+    stream and ``handle.wait()`` makes the compute stream wait for it."""
     if world_size > 1:
-        dist.all_reduce(flat_grad, op=dist.ReduceOp.SUM)
-    return flat_grad
+        w = dist.all_reduce(flat_grad, op=dist.ReduceOp.SUM, async_op=async_op)
+        return w if async_op else flat_grad
+    return None if async_op else flat_grad
 
 
 def broadcast_parameters(flat_param, world_size, src=0):

@@ -42,6 +42,10 @@ SIGNATURES = {
     "agcn_gcn_project_bwd_weight_workspace": (_Z, [_I, _I, _I, _I, _I]),
     "agcn_gcn_project_bwd_weight": (_I, [_P, _P, _P, _P, _P, _Z, _I, _I, _I, _I, _I, _P]),
     "agcn_adjacency_fwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
+    "agcn_adjacency_fused_supported": (_I, [_I, _I, _I, _I]),
+    "agcn_adjacency_fused_workspace": (_Z, [_I, _I]),
+    "agcn_adjacency_fused_fwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _Z, _I, _I, _I, _I, _I, _P]),
+    "agcn_adjacency_fused_bwd_scores": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _Z, _I, _I, _I, _I, _I, _P]),
     "agcn_adjacency_bwd_softmax": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
     "agcn_adjacency_bwd_scores": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
     "agcn_colsum_scratch_bytes": (_Z, [_I]),

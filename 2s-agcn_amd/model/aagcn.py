@@ -135,7 +135,7 @@ class TCNUnit(nn.Module):
     def forward(self, x):
         _require_gpu(x, 'aagcn.TCNUnit')
         y = ops.UnitTCNFunction.apply(x, self.conv.weight, self.conv.bias, *_bn_args(self.bn), self.stride,
-                                      self.training)
+                                      self.training, ops.sync_of(self.bn))
         _bn_tick(self.bn, self.training)
         return y
 
@@ -192,10 +192,11 @@ class GCNUnit(nn.Module):
                 ws += [self.agcn.conv_a[i].weight, self.agcn.conv_b[i].weight]
                 bs += [self.agcn.conv_a[i].bias, self.agcn.conv_b[i].bias]
             y = ops.UnitGCNFunction.apply(x, None, self.agcn.PA, torch.cat(ws, 0), torch.cat(bs, 0), wd, bd,
-                                          *_bn_args(self.bn), *dn, self.training, self.agcn.alpha, True)
+                                          *_bn_args(self.bn), *dn, self.training, self.agcn.alpha, True,
+                                          ops.sync_of(self.bn))
         else:
             y = ops.UnitGCNFunction.apply(x, self.agcn.A, None, None, None, wd, bd, *_bn_args(self.bn), *dn,
-                                          self.training, None, False)
+                                          self.training, None, False, ops.sync_of(self.bn))
         _bn_tick(self.bn, self.training)
         if isinstance(self.down, nn.Sequential):
             _bn_tick(self.down[1], self.training)
@@ -235,7 +236,8 @@ class TCNGCNUnit(nn.Module):
         else:
             rargs = (None,) * 6
         out = ops.TCNResidualFunction.apply(y, x if self.res_mode else None, t.conv.weight, t.conv.bias,
-                                            *_bn_args(t.bn), self.res_mode, *rargs, self.stride, self.training)
+                                            *_bn_args(t.bn), self.res_mode, *rargs, self.stride, self.training,
+                                            ops.sync_of(t.bn))
         _bn_tick(t.bn, self.training)
         if self.res_mode == 2:
             _bn_tick(self.residual.bn, self.training)
@@ -318,12 +320,6 @@ class BaseModel(nn.Module):
         return self.fc(self.drop_out(x))
 
     def forward(self, x):
-        import torch.distributed as dist
-        bn = self.l1.gcn1.bn
-        if isinstance(bn, nn.SyncBatchNorm) and dist.is_available() and dist.is_initialized():
-            ops.set_sync_bn(dist.get_world_size(bn.process_group), bn.process_group)   # see agcn.follow_sync_batchnorm
-        else:
-            ops.set_sync_bn(1)
         size = x.size()
         x = self.forward_preprocess(x, size)
         x = self.forward_model_backbone(x, size)

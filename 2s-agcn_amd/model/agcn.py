@@ -56,20 +56,6 @@ def _bn_args(bn):
     return bn.weight, bn.bias, bn.running_mean, bn.running_var
 
 
-def follow_sync_batchnorm(model):
-    """The reference's DDP path converts every BatchNorm with ``SyncBatchNorm.convert_sync_batchnorm`` before wrapping
-    the model (utils/processor.py:295).  The HIP units only borrow the BN modules' parameters, so the conversion is
-    honoured here: if the unit BNs have become SyncBatchNorm and a process group is up, the HIP BatchNorm stages
-    all-reduce their sums (ops.set_sync_bn).  Called once per forward of the top-level model; cheap."""
-    import torch.distributed as dist
-    bn = model.l1.gcn1.bn
-    if isinstance(bn, nn.SyncBatchNorm) and dist.is_available() and dist.is_initialized():
-        group = bn.process_group
-        ops.set_sync_bn(dist.get_world_size(group), group)
-    else:
-        ops.set_sync_bn(1)
-
-
 def _bn_tick(bn, training):
     if training and bn.num_batches_tracked is not None:
         bn.num_batches_tracked.add_(1)
@@ -92,7 +78,7 @@ class unit_tcn(nn.Module):
     def forward(self, x):
         _require_gpu(x, 'unit_tcn')
         y = ops.UnitTCNFunction.apply(x, self.conv.weight, self.conv.bias, *_bn_args(self.bn), self.stride,
-                                      self.training)
+                                      self.training, ops.sync_of(self.bn))
         _bn_tick(self.bn, self.training)
         return y
 
@@ -158,7 +144,7 @@ class unit_gcn(nn.Module):
 
     def forward(self, x):
         _require_gpu(x, 'unit_gcn')
-        y = ops.UnitGCNFunction.apply(x, *self.packed_args(), self.training, None, True)
+        y = ops.UnitGCNFunction.apply(x, *self.packed_args(), self.training, None, True, ops.sync_of(self.bn))
         self.tick()
         return y
 
@@ -189,7 +175,7 @@ class TCN_GCN_unit(nn.Module):
         else:
             rargs = (None,) * 6
         y = ops.TCNGCNUnitFunction.apply(x, *self.gcn1.packed_args(), t.conv.weight, t.conv.bias, *_bn_args(t.bn),
-                                         self.res_mode, *rargs, self.stride, self.training)
+                                         self.res_mode, *rargs, self.stride, self.training, ops.sync_of(t.bn))
         self.gcn1.tick()
         _bn_tick(t.bn, self.training)
         if self.res_mode == 2:
@@ -221,7 +207,6 @@ class Model(nn.Module):
         bn_init(self.data_bn, 1)
 
     def forward(self, x):
-        follow_sync_batchnorm(self)
         N, C, T, V, M = x.size()
         x = x.permute(0, 4, 3, 1, 2).contiguous().view(N, M * V * C, T)
         x = self.data_bn(x)

@@ -105,6 +105,37 @@ def adjacency_fwd(tp, A, PA, alpha=None):
     return P, adj
 
 
+def adjacency_fused_supported(C, Ci, T, V):
+    return bool(_L().agcn_adjacency_fused_supported(int(C), int(Ci), int(T), int(V)))
+
+
+def adjacency_recompute():
+    """Backward policy of the adaptive branch: recompute theta/phi on chip from x (AGCN_ADJ_RECOMPUTE=1: nothing of
+    size 6*Ci*T*V is kept per layer) or re-read the copy the fused forward leaves behind as a by-product (default:
+    measured faster on MI355X)."""
+    import os
+    return os.environ.get('AGCN_ADJ_RECOMPUTE', '0') == '1'
+
+
+def adjacency_fused_fwd(x, wab, bab, A, PA, alpha=None, keep_tp=False):
+    """P, adj straight from x: [theta;phi] = wab.x + bab is formed and reduced on chip (no tp round trip); wab
+    (6Ci, C[,1,1]).  keep_tp: also return theta/phi, written once as a by-product (never re-read by the forward)."""
+    N, C, T, V = x.shape
+    Ci = wab.shape[0] // 6
+    tp = _empty((N, 6 * Ci, T, V), x) if keep_tp else None
+    nt = _L().agcn_scores_num_tiles(V, T)
+    spart = _empty((N, 3, nt, V, V), x)
+    P = _empty((N, 3, V, V), x)
+    adj = _empty((N, 3, V, V), x)
+    nb = _L().agcn_adjacency_fused_workspace(C, Ci)
+    ws = _ws(nb, x)
+    _lib.check(_L().agcn_adjacency_fused_fwd(_lib.ptr(x), _lib.ptr(wab.reshape(6 * Ci, C)), _lib.ptr(bab), _lib.ptr(A),
+                                             _lib.ptr(PA), _lib.ptr(alpha), _lib.ptr(tp), _lib.ptr(spart), _lib.ptr(P),
+                                             _lib.ptr(adj), ws.data_ptr(), nb, N, C, Ci, T, V, _lib.stream()),
+               "agcn_adjacency_fused_fwd")
+    return (P, adj, tp) if keep_tp else (P, adj)
+
+
 def aggregate_project_fwd(x, adj, wcat, bias, want_stats=False):
     """y = sum_i Wd_i (x . adj_i) + bias ; wcat: (Cout, 3C) = [Wd_0 | Wd_1 | Wd_2]."""
     N, C, T, V = x.shape
@@ -165,11 +196,12 @@ def project_bwd_weight(dy, x, adj, Cout):
     return dw
 
 
-def adjacency_bwd(dy, wcat, x, tp, P, alpha=None):
-    """Gradient of the adaptive adjacency branch.  Returns dPA (3,V,V), dtp (N,6Ci,T,V), dbab (6Ci), dalpha."""
+def adjacency_bwd(dy, wcat, x, tp, P, alpha=None, wab=None, bab=None):
+    """Gradient of the adaptive adjacency branch.  Returns dPA (3,V,V), dtp (N,6Ci,T,V), dbab (6Ci), dalpha.
+    tp = None: theta/phi were never stored (adjacency_fused_fwd); they are recomputed from x, wab, bab on chip."""
     N, C, T, V = x.shape
     Cout = wcat.shape[0]
-    Ci = tp.shape[1] // 6
+    Ci = (tp.shape[1] if tp is not None else wab.shape[0]) // 6
     nslots = _L().agcn_dadj_num_slots(C, V, T)
     dpart = _empty((N, 3, nslots, V, V), x)
     ws, nb = _gcn_ws(C, Cout, T, V, x)
@@ -183,13 +215,21 @@ def adjacency_bwd(dy, wcat, x, tp, P, alpha=None):
                                                _lib.ptr(dS), _lib.ptr(dPA), _lib.ptr(dal_part), N, Ci, T, V, nslots,
                                                _lib.stream()), "agcn_adjacency_bwd_softmax")
     nt = _L().agcn_scores_num_tiles(V, T)
-    dtp = _empty(tuple(tp.shape), x)
+    dtp = _empty((N, 6 * Ci, T, V), x)
     dbpart = _empty((N * nt, 6 * Ci), x)
     dbab = _empty((6 * Ci,), x)
     scratch = _scratch(6 * Ci, x)
-    _lib.check(_L().agcn_adjacency_bwd_scores(_lib.ptr(tp), _lib.ptr(dS), _lib.ptr(dtp), _lib.ptr(dbpart),
-                                              scratch.data_ptr(), _lib.ptr(dbab), N, Ci, T, V, _lib.stream()),
-               "agcn_adjacency_bwd_scores")
+    if tp is None:
+        nb = _L().agcn_adjacency_fused_workspace(C, Ci)
+        ws = _ws(nb, x)
+        _lib.check(_L().agcn_adjacency_fused_bwd_scores(
+            _lib.ptr(x), _lib.ptr(wab.reshape(6 * Ci, C)), _lib.ptr(bab), _lib.ptr(dS), _lib.ptr(dtp), _lib.ptr(dbpart),
+            scratch.data_ptr(), _lib.ptr(dbab), ws.data_ptr(), nb, N, C, Ci, T, V, _lib.stream()),
+            "agcn_adjacency_fused_bwd_scores")
+    else:
+        _lib.check(_L().agcn_adjacency_bwd_scores(_lib.ptr(tp), _lib.ptr(dS), _lib.ptr(dtp), _lib.ptr(dbpart),
+                                                  scratch.data_ptr(), _lib.ptr(dbab), N, Ci, T, V, _lib.stream()),
+                   "agcn_adjacency_bwd_scores")
     dalpha = dal_part.sum() if dal_part is not None else None
     return dPA, dtp, dbab, dalpha, dadj
 
@@ -199,16 +239,29 @@ class BNState:
     __slots__ = ("mean", "invstd", "scale", "shift")
 
 
-# BatchNorm statistics policy of the HIP layers.  world == 1: per replica (reference nn.DataParallel semantics,
-# utils/processor.py:336-343; the default).  world > 1: synchronised over the process group like the reference's DDP
-# path (SyncBatchNorm.convert_sync_batchnorm, processor.py:295): the per-channel sums are all-reduced between the
-# two stages of the forward statistics and of the backward (one small collective each; ``dp.enable_sync_bn``).
-_SYNC_BN = {"world": 1, "group": None}
+class SyncBN:
+    """BatchNorm statistics policy of ONE unit's HIP BatchNorm stages, carried by the calling module and stored on the
+    autograd context (no process-global state: two models with different policies can live in one process).
+    ``None`` = per replica (reference nn.DataParallel semantics, utils/processor.py:336-343).  ``SyncBN(world, group)``
+    = synchronised over the process group like the reference's DDP path (SyncBatchNorm.convert_sync_batchnorm,
+    processor.py:295): the per-channel sums are all-reduced between the two stages of the forward statistics (ONE
+    collective for the main and the down/residual BatchNorm together) and of the backward (one collective)."""
+    __slots__ = ("world", "group")
+
+    def __init__(self, world, group=None):
+        self.world, self.group = int(world), group
 
 
-def set_sync_bn(world, group=None):
-    _SYNC_BN["world"] = int(world)
-    _SYNC_BN["group"] = group
+def sync_of(bn_module):
+    """SyncBN policy implied by a BatchNorm module: the reference converts the model with
+    ``SyncBatchNorm.convert_sync_batchnorm`` before DDP (processor.py:295); the HIP units only borrow the BN modules'
+    parameters, so the conversion is honoured by looking at the module's class."""
+    import torch.distributed as dist
+    if isinstance(bn_module, torch.nn.SyncBatchNorm) and dist.is_available() and dist.is_initialized():
+        world = dist.get_world_size(bn_module.process_group)
+        if world > 1:
+            return SyncBN(world, bn_module.process_group)
+    return None
 
 
 def _colsum(slab, nslots, width):
@@ -219,22 +272,35 @@ def _colsum(slab, nslots, width):
     return out
 
 
-def _allreduce_sum(t):
+def _allreduce_sum(t, sync):
     import torch.distributed as dist
-    dist.all_reduce(t, op=dist.ReduceOp.SUM, group=_SYNC_BN["group"])
+    dist.all_reduce(t, op=dist.ReduceOp.SUM, group=sync.group)
     return t
 
 
+def sync_stats(stats_parts, count, sync):
+    """Global (sum, sumsq) of several BatchNorm stages of one unit with ONE all-reduce: every slab is reduced over its
+    slots locally, the per-channel sums travel in one buffer, and each stage gets back a 1-slot slab.  Every rank must
+    hold the same number of elements per channel (equal per-rank batches: the trainer's sampler pads like torch's
+    DistributedSampler), so the global count is count * world.  Returns [slab (1,2,C) ...]."""
+    sums = [_colsum(sp, sp.shape[0], sp.shape[1] * sp.shape[2]) for sp in stats_parts]
+    buf = torch.cat(sums) if len(sums) > 1 else sums[0]
+    _allreduce_sum(buf, sync)
+    out, o = [], 0
+    for sp in stats_parts:
+        w = sp.shape[1] * sp.shape[2]
+        out.append(buf[o:o + w].view(1, 2, sp.shape[2]))
+        o += w
+    return out
+
+
 def bn_train_coeffs(stats_part, count, gamma, beta, running_mean, running_var, momentum=BN_MOMENTUM, eps=BN_EPS):
+    """stats_part: (slots, 2, C) partial (sum, sumsq); count: elements per channel behind them (python number)."""
     C = gamma.numel()
     st = BNState()
     st.mean, st.invstd = _empty((C,), gamma), _empty((C,), gamma)
     st.scale, st.shift = _empty((C,), gamma), _empty((C,), gamma)
     nslots = stats_part.shape[0]
-    if _SYNC_BN["world"] > 1:      # global (sum, sumsq): reduce the slots here, all-reduce, finalize over the global count
-        stats_part = _allreduce_sum(_colsum(stats_part, nslots, 2 * C)).view(1, 2, C)
-        nslots = 1
-        count = count * _SYNC_BN["world"]
     scratch = _scratch(2 * C, gamma)
     _lib.check(_L().agcn_bn_stats_finalize(_lib.ptr(stats_part), nslots, C, float(count), _lib.ptr(gamma),
                                            _lib.ptr(beta), _lib.ptr(running_mean), _lib.ptr(running_var),
@@ -270,7 +336,7 @@ def bn_act_fwd(y1, st1, r=None, st2=None, relu=True, want_bits=False):
     return (out, bits) if want_bits else out
 
 
-def bn_bwd(dout, mask, y1, gamma1, st1, y2=None, gamma2=None, st2=None):
+def bn_bwd(dout, mask, y1, gamma1, st1, y2=None, gamma2=None, st2=None, sync=None, gcount=None):
     """Backward through out = relu(bn1(y1) [+ bn2(y2)] [+ identity]) in train mode.  ``mask``: the fp32 output tensor
     (positive elements pass) or the int32 sign bit mask of ``bn_act_fwd(..., want_bits=True)``; None = no ReLU.
     Returns dy1, dgamma1, dbeta1, dy2, dgamma2, dbeta2 (branch-2 entries None without y2)."""
@@ -283,10 +349,9 @@ def bn_bwd(dout, mask, y1, gamma1, st1, y2=None, gamma2=None, st2=None):
     if y2 is not None:
         dy2 = torch.empty_like(y2)
         dg2, db2 = _empty((C,), y1), _empty((C,), y1)
-    world = _SYNC_BN["world"]
     mbits = int(mask is not None and mask.dtype == torch.int32)
     mptr = _lib.ptr_bits(mask) if mbits else _lib.ptr(mask)
-    if world <= 1:
+    if sync is None:
         _lib.check(_L().agcn_bn_bwd(
             _lib.ptr(dout), mptr, mbits, _lib.ptr(y1), _lib.ptr(gamma1), _lib.ptr(st1.mean), _lib.ptr(st1.invstd),
             _lib.ptr(y2), _lib.ptr(gamma2), _lib.ptr(st2.mean) if st2 else None, _lib.ptr(st2.invstd) if st2 else None,
@@ -295,9 +360,12 @@ def bn_bwd(dout, mask, y1, gamma1, st1, y2=None, gamma2=None, st2=None):
     else:
         _lib.check(_L().agcn_bn_bwd_reduce(_lib.ptr(dout), mptr, mbits, _lib.ptr(y1), _lib.ptr(y2),
                                            _lib.ptr(part), N, C, T * V, _lib.stream()), "agcn_bn_bwd_reduce")
-        sums = _allreduce_sum(_colsum(part, N, 3 * C))
+        # one collective for both branches; dgamma/dbeta come out as GLOBAL sums, scaled by 1/world so that the
+        # gradient average of the data-parallel step restores them (every rank holds the same value)
+        sums = _allreduce_sum(_colsum(part, N, 3 * C), sync)
+        total = float(gcount) if gcount is not None else float(N * T * V * sync.world)
         _lib.check(_L().agcn_bn_bwd_apply(
-            _lib.ptr(sums), 1, float(N * T * V * world), 1.0 / world, _lib.ptr(dout), mptr, mbits, _lib.ptr(y1),
+            _lib.ptr(sums), 1, total, 1.0 / sync.world, _lib.ptr(dout), mptr, mbits, _lib.ptr(y1),
             _lib.ptr(gamma1), _lib.ptr(st1.mean), _lib.ptr(st1.invstd), _lib.ptr(y2), _lib.ptr(gamma2),
             _lib.ptr(st2.mean) if st2 else None, _lib.ptr(st2.invstd) if st2 else None, _lib.ptr(coef), _lib.ptr(dy1),
             _lib.ptr(dg1), _lib.ptr(db1), _lib.ptr(dy2), _lib.ptr(dg2), _lib.ptr(db2), N, C, T * V, _lib.stream()),
@@ -313,38 +381,55 @@ class _Ctx:
     pass
 
 
-def _bn_coeffs(training, stats, count, w, b, rm, rv):
-    if training:
-        return bn_train_coeffs(stats, count, w, b, rm, rv)
-    return bn_eval_coeffs(w, b, rm, rv)
+def _bn_coeffs(training, stats, count, bns, sync=None):
+    """Coefficients of the BatchNorm stages of one unit (main [+ down/residual]): ``stats`` / ``bns`` are parallel
+    lists of partial-sum slabs and (weight, bias, running_mean, running_var).  Returns ([BNState ...], global count)."""
+    if not training:
+        return [bn_eval_coeffs(*bn) for bn in bns], count
+    if sync is not None:
+        stats = sync_stats(stats, count, sync)
+        count = count * sync.world
+    return [bn_train_coeffs(sp, count, *bn) for sp, bn in zip(stats, bns)], count
 
 
-def gcn_forward(c, x, A, PA, wab, bab, wd, bd, bn, down, training, alpha=None, adaptive=True):
+def gcn_forward(c, x, A, PA, wab, bab, wd, bd, bn, down, training, alpha=None, adaptive=True, sync=None,
+                need_bwd=True):
     """unit_gcn.forward (reference agcn.py:92-109) and AAGCN's GCNUnit core (aagcn.py:164-177, 264-266).
     wab: (6Ci, C, 1, 1) rows [a0|b0|a1|b1|a2|b2]; wd: (Cout, 3C); bd: summed conv_d biases;
     bn = (weight, bias, running_mean, running_var); down = None | (w, b, bn_w, bn_b, bn_rm, bn_rv).
     AGCN: adj = P + A + PA.  AAGCN: A = None, adj = PA + alpha*P.  adaptive=False (NonAdaptiveGCN): adj = A."""
     N, C, T, V = x.shape
     count = N * T * V
-    if adaptive:
+    if adaptive and adjacency_fused_supported(C, wab.shape[0] // 6, T, V):
+        # theta/phi are formed and reduced on chip.  A training forward either keeps nothing (the backward recomputes
+        # them, adjacency_bwd with tp = None) or lets the kernel drop a copy for the backward to re-read.
+        keep = training and need_bwd and not adjacency_recompute()
+        if keep:
+            P, adj, tp = adjacency_fused_fwd(x, wab, bab, A, PA, alpha, keep_tp=True)
+        else:
+            tp = None
+            P, adj = adjacency_fused_fwd(x, wab, bab, A, PA, alpha)
+    elif adaptive:
         tp, _ = conv_fwd(x, wab, bab)
         P, adj = adjacency_fwd(tp, A, PA, alpha)
     else:
         tp = P = None
         adj = A.unsqueeze(0).expand(N, 3, V, V).contiguous()
     ypre, st = aggregate_project_fwd(x, adj, wd, bd, want_stats=training)
-    bn1 = _bn_coeffs(training, st, count, *bn)
     dpre = bn2 = None
     if down is not None:
         dpre, st2 = conv_fwd(x, down[0], down[1], want_stats=training)
-        bn2 = _bn_coeffs(training, st2, count, *down[2:])
+        (bn1, bn2), gcount = _bn_coeffs(training, [st, st2], count, [bn, down[2:]], sync)
         out, bits = bn_act_fwd(ypre, bn1, dpre, bn2, relu=True, want_bits=True)
     else:
+        (bn1,), gcount = _bn_coeffs(training, [st], count, [bn], sync)
         out, bits = bn_act_fwd(ypre, bn1, x, None, relu=True, want_bits=True)
+    c.g_sync, c.g_count = sync, gcount
     c.g_bits = bits          # sign bit mask of `out` for the BatchNorm backward (32x less traffic than `out`)
     c.g_x, c.g_tp, c.g_P, c.g_adj, c.g_ypre, c.g_dpre, c.g_out = x, tp, P, adj, ypre, dpre, out
     c.g_bn1, c.g_bn2 = bn1, bn2
     c.g_params = (wab, wd, bn[0], down[0] if down is not None else None, down[2] if down is not None else None)
+    c.g_bab = bab
     c.g_alpha, c.g_adaptive = alpha, adaptive
     return out
 
@@ -355,11 +440,12 @@ def gcn_backward(c, dout, extra_add=None, extra_mask=None):
     x, tp, P, adj, ypre, dpre, out = c.g_x, c.g_tp, c.g_P, c.g_adj, c.g_ypre, c.g_dpre, c.g_out
     wab, wd, gamma1, wdown, gamma2 = c.g_params
     Cout = wd.shape[0]
-    dypre, dg1, db1, ddpre, dg2, db2 = bn_bwd(dout, c.g_bits, ypre, gamma1, c.g_bn1, dpre, gamma2, c.g_bn2)
+    dypre, dg1, db1, ddpre, dg2, db2 = bn_bwd(dout, c.g_bits, ypre, gamma1, c.g_bn1, dpre, gamma2, c.g_bn2,
+                                              sync=c.g_sync, gcount=c.g_count)
     dwd = project_bwd_weight(dypre, x, adj, Cout)
     dPA = dwab = dbab = dalpha = dtp = None
     if c.g_adaptive:      # adjacency branch first: its dtp rides along in the dx kernel where that is supported
-        dPA, dtp, dbab, dalpha, _ = adjacency_bwd(dypre, wd, x, tp, P, c.g_alpha)
+        dPA, dtp, dbab, dalpha, _ = adjacency_bwd(dypre, wd, x, tp, P, c.g_alpha, wab, c.g_bab)
         dwab = conv_bwd_weight(dtp, x, wab.shape)
     fuse = dtp is not None and fused_bwd_data_supported(x.shape[1], Cout, x.shape[3])
     ftp = dict(dtp=dtp, wab=wab) if fuse else {}
@@ -378,7 +464,7 @@ def gcn_backward(c, dout, extra_add=None, extra_mask=None):
     return dx, dPA, dwab, dbab, dwd, dg1, db1, dwdown, dg2, db2
 
 
-def tcn_forward(c, g, w, b, bn, stride, res_x, res, relu, training):
+def tcn_forward(c, g, w, b, bn, stride, res_x, res, relu, training, sync=None):
     """unit_tcn.forward (reference agcn.py:48-50) optionally fused with the TCN_GCN_unit tail
     relu(tcn(g) + residual(x)) (agcn.py:127-129).  res = None (no residual) | 'identity' |
     (w, b, bn_w, bn_b, bn_rm, bn_rv) for the unit_tcn(kernel_size=1, stride) residual."""
@@ -386,16 +472,15 @@ def tcn_forward(c, g, w, b, bn, stride, res_x, res, relu, training):
     zpre, st = conv_fwd(g, w, b, stride, want_stats=training)
     To = zpre.shape[2]
     count = N * To * V
-    bn1 = _bn_coeffs(training, st, count, *bn)
     rpre = bn2 = None
-    if res is None:
-        out, bits = bn_act_fwd(zpre, bn1, None, None, relu=relu, want_bits=True)
-    elif isinstance(res, str):
-        out, bits = bn_act_fwd(zpre, bn1, res_x, None, relu=relu, want_bits=True)
+    if res is None or isinstance(res, str):
+        (bn1,), gcount = _bn_coeffs(training, [st], count, [bn], sync)
+        out, bits = bn_act_fwd(zpre, bn1, None if res is None else res_x, None, relu=relu, want_bits=True)
     else:
         rpre, st2 = conv_fwd(res_x, res[0], res[1], stride, want_stats=training)
-        bn2 = _bn_coeffs(training, st2, count, *res[2:])
+        (bn1, bn2), gcount = _bn_coeffs(training, [st, st2], count, [bn, res[2:]], sync)
         out, bits = bn_act_fwd(zpre, bn1, rpre, bn2, relu=relu, want_bits=True)
+    c.t_sync, c.t_count = sync, gcount
     c.t_bits = bits
     c.t_g, c.t_zpre, c.t_rpre, c.t_out, c.t_bn1, c.t_bn2 = g, zpre, rpre, out, bn1, bn2
     c.t_resx, c.t_res_identity = res_x, isinstance(res, str)
@@ -408,7 +493,8 @@ def tcn_backward(c, dout):
     """Returns dg, dw, dgamma, dbeta, (drpre, dw_res, dgamma_res, dbeta_res)."""
     w, gamma1, wres, gamma2 = c.t_params
     mask = c.t_bits if c.t_relu else None
-    dzpre, dg1, db1, drpre, dg2, db2 = bn_bwd(dout, mask, c.t_zpre, gamma1, c.t_bn1, c.t_rpre, gamma2, c.t_bn2)
+    dzpre, dg1, db1, drpre, dg2, db2 = bn_bwd(dout, mask, c.t_zpre, gamma1, c.t_bn1, c.t_rpre, gamma2, c.t_bn2,
+                                              sync=c.t_sync, gcount=c.t_count)
     dw = conv_bwd_weight(dzpre, c.t_g, w.shape, c.t_stride)
     dg = conv_bwd_data(dzpre, w, c.t_g.shape, c.t_stride)
     dwres = None
@@ -429,11 +515,11 @@ class UnitGCNFunction(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, A, PA, wab, bab, wd, bd, bn_w, bn_b, bn_rm, bn_rv, down_w, down_b, dbn_w, dbn_b, dbn_rm,
-                dbn_rv, training, alpha=None, adaptive=True):
+                dbn_rv, training, alpha=None, adaptive=True, sync=None):
         c = _Ctx()
         down = None if down_w is None else (down_w, down_b, dbn_w, dbn_b, dbn_rm, dbn_rv)
         out = gcn_forward(c, x.contiguous(), A, PA, wab, bab, wd, bd, (bn_w, bn_b, bn_rm, bn_rv), down, training,
-                          alpha, adaptive)
+                          alpha, adaptive, sync, need_bwd=any(ctx.needs_input_grad))
         ctx.c, ctx.training = c, training
         ctx.has_down = down is not None
         return out
@@ -450,16 +536,17 @@ class UnitGCNFunction(torch.autograd.Function):
             dalpha = dalpha.reshape(1)
         ctx.c = None
         return (dx, None, dPA, dwab, dbab, dwd, dbd, dg1, db1, None, None, dwdown, dbdown, dg2, db2, None, None, None,
-                dalpha, None)
+                dalpha, None, None)
 
 
 class UnitTCNFunction(torch.autograd.Function):
     """unit_tcn (no residual, no ReLU): args (x, w, b, bn_w, bn_b, bn_rm, bn_rv, stride, training)"""
 
     @staticmethod
-    def forward(ctx, x, w, b, bn_w, bn_b, bn_rm, bn_rv, stride, training):
+    def forward(ctx, x, w, b, bn_w, bn_b, bn_rm, bn_rv, stride, training, sync=None):
         c = _Ctx()
-        out = tcn_forward(c, x.contiguous(), w, b, (bn_w, bn_b, bn_rm, bn_rv), stride, None, None, False, training)
+        out = tcn_forward(c, x.contiguous(), w, b, (bn_w, bn_b, bn_rm, bn_rv), stride, None, None, False, training,
+                          sync)
         ctx.c, ctx.training = c, training
         return out
 
@@ -469,7 +556,7 @@ class UnitTCNFunction(torch.autograd.Function):
         dg, dw, dg1, db1, _, _, _, _ = tcn_backward(ctx.c, dout.contiguous())
         dbias = torch.zeros(dw.shape[0], dtype=torch.float32, device=dout.device)
         ctx.c = None
-        return dg, dw, dbias, dg1, db1, None, None, None, None
+        return dg, dw, dbias, dg1, db1, None, None, None, None, None
 
 
 class TCNResidualFunction(torch.autograd.Function):
@@ -479,11 +566,11 @@ class TCNResidualFunction(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, g, x, w, b, bn_w, bn_b, bn_rm, bn_rv, res_mode, rw, rb, rbn_w, rbn_b, rbn_rm, rbn_rv, stride,
-                training):
+                training, sync=None):
         c = _Ctx()
         res = None if res_mode == 0 else ('identity' if res_mode == 1 else (rw, rb, rbn_w, rbn_b, rbn_rm, rbn_rv))
         x = x.contiguous() if x is not None else None
-        out = tcn_forward(c, g.contiguous(), w, b, (bn_w, bn_b, bn_rm, bn_rv), stride, x, res, True, training)
+        out = tcn_forward(c, g.contiguous(), w, b, (bn_w, bn_b, bn_rm, bn_rv), stride, x, res, True, training, sync)
         ctx.c, ctx.training, ctx.res_mode, ctx.stride = c, training, res_mode, stride
         ctx.x_shape = tuple(x.shape) if x is not None else None
         return out
@@ -503,7 +590,7 @@ class TCNResidualFunction(torch.autograd.Function):
             dx = conv_bwd_data(drpre, c.t_params[2], ctx.x_shape, ctx.stride)
         ctx.c = None
         return (dg, dx, dw, zb(dw.shape[0]), dg1, db1, None, None, None,
-                dwres, zb(dwres.shape[0]) if ctx.res_mode == 2 else None, dg2, db2, None, None, None, None)
+                dwres, zb(dwres.shape[0]) if ctx.res_mode == 2 else None, dg2, db2, None, None, None, None, None)
 
 
 class TCNGCNUnitFunction(torch.autograd.Function):
@@ -512,18 +599,19 @@ class TCNGCNUnitFunction(torch.autograd.Function):
 
     args: x, A, PA, wab, bab, wd, bd, gbn_w, gbn_b, gbn_rm, gbn_rv, down_w, down_b, dbn_w, dbn_b, dbn_rm, dbn_rv,
           tw, tb, tbn_w, tbn_b, tbn_rm, tbn_rv, res_mode(0 none,1 identity,2 conv), rw, rb, rbn_w, rbn_b, rbn_rm,
-          rbn_rv, stride, training"""
+          rbn_rv, stride, training, sync (SyncBN policy or None)"""
 
     @staticmethod
     def forward(ctx, x, A, PA, wab, bab, wd, bd, gbn_w, gbn_b, gbn_rm, gbn_rv, down_w, down_b, dbn_w, dbn_b, dbn_rm,
                 dbn_rv, tw, tb, tbn_w, tbn_b, tbn_rm, tbn_rv, res_mode, rw, rb, rbn_w, rbn_b, rbn_rm, rbn_rv, stride,
-                training):
+                training, sync=None):
         c = _Ctx()
         x = x.contiguous()
         down = None if down_w is None else (down_w, down_b, dbn_w, dbn_b, dbn_rm, dbn_rv)
-        g = gcn_forward(c, x, A, PA, wab, bab, wd, bd, (gbn_w, gbn_b, gbn_rm, gbn_rv), down, training)
+        g = gcn_forward(c, x, A, PA, wab, bab, wd, bd, (gbn_w, gbn_b, gbn_rm, gbn_rv), down, training, sync=sync,
+                        need_bwd=any(ctx.needs_input_grad))
         res = None if res_mode == 0 else ('identity' if res_mode == 1 else (rw, rb, rbn_w, rbn_b, rbn_rm, rbn_rv))
-        out = tcn_forward(c, g, tw, tb, (tbn_w, tbn_b, tbn_rm, tbn_rv), stride, x, res, True, training)
+        out = tcn_forward(c, g, tw, tb, (tbn_w, tbn_b, tbn_rm, tbn_rv), stride, x, res, True, training, sync)
         ctx.c, ctx.training, ctx.has_down, ctx.res_mode, ctx.stride = c, training, down is not None, res_mode, stride
         return out
 
@@ -546,4 +634,4 @@ class TCNGCNUnitFunction(torch.autograd.Function):
         return (dx, None, dPA, dwab, dbab, dwd, zb(dwd.shape[0]), dg1, db1, None, None,
                 dwdown, zb(dwdown.shape[0]) if ctx.has_down else None, dg2, db2, None, None,
                 dtw, zb(dtw.shape[0]), dtg, dtb, None, None, None,
-                drw, zb(drw.shape[0]) if ctx.res_mode == 2 else None, drg, drb, None, None, None, None)
+                drw, zb(drw.shape[0]) if ctx.res_mode == 2 else None, drg, drb, None, None, None, None, None)

@@ -69,9 +69,11 @@ def get_parser():
     p.add_argument('--only-train-part', type=str2bool, default=False)
     p.add_argument('--only-train-epoch', type=int, default=0)
     p.add_argument('--ddp', type=str2bool, default=False)
-    p.add_argument('--sync-bn', type=str2bool, default=False,
-                   help='synchronise BatchNorm statistics over the ranks (reference DDP path, processor.py:295); '
-                        'default: per-replica statistics (reference nn.DataParallel path)')
+    p.add_argument('--sync-bn', type=str2bool, default=None,
+                   help='synchronise BatchNorm statistics over the ranks.  Default: on whenever more than one process '
+                        'trains (the reference\'s only multi-process path always converts to SyncBatchNorm, '
+                        'processor.py:295); "--sync-bn false" opts out to per-replica statistics (the semantics of '
+                        'the reference\'s single-process nn.DataParallel path, processor.py:336-343)')
     p.add_argument('--world-size', type=int, default=1)
     p.add_argument('--max-steps-per-epoch', type=int, default=0, help='0 = whole epoch (synthetic smoke runs)')
     return p
@@ -142,7 +144,9 @@ class Processor:
         self.global_step = 0
         self.load_model()
         self.load_data()
-        if getattr(arg, 'sync_bn', False):
+        sync_bn = getattr(arg, 'sync_bn', None)
+        self.sync_bn = (self.world > 1) if sync_bn is None else (bool(sync_bn) and self.world > 1)
+        if self.sync_bn:
             self.model = _dp.enable_sync_bn(self.model, self.world)
         self.engine = TrainEngine(self.model, base_lr=arg.base_lr, momentum=0.9, nesterov=arg.nesterov,
                                   weight_decay=arg.weight_decay, max_grad_norm=1.0, world_size=self.world)

@@ -100,6 +100,22 @@ int agcn_gcn_dadj(const float* dy, const float* wcat, const float* x, float* dad
  * Outputs P (softmax, kept for the backward) and adj, both (N,3,V,V). */
 int agcn_adjacency_fwd(const float* tp, const float* A, const float* PA, const float* alpha, float* spart, float* P,
                        float* adj, int N, int Ci, int T, int V, void* stream);
+/* The same WITHOUT the theta/phi tensor in HBM (SURVEY Appendix A "kernel A"): x (N,C,T,V) is read once per
+ * workgroup tile, [theta;phi] = wab . x + bab (wab: (6*Ci, C) stacked conv_a/conv_b weights, rows as tp above) lives in
+ * accumulators/LDS only and is reduced into spart on the spot; then the finalize above.  _bwd_scores recomputes the
+ * tile and writes dtp / db exactly as agcn_adjacency_bwd_scores does from a stored tp.  tp_out (may be NULL): if
+ * given, the forward also leaves theta/phi (N, 6*Ci, T, V) in HBM as a by-product (coalesced rows from the LDS tile)
+ * for a backward that prefers re-reading to recomputing (measured faster on MI355X).  workspace: packed split
+ * weights, agcn_adjacency_fused_workspace(C, Ci) bytes.  agcn_adjacency_fused_supported: Ci in {16,32,64}, bf16x6
+ * arithmetic (AGCN_GEMM default); otherwise use agcn_conv_fwd + agcn_adjacency_fwd. */
+int agcn_adjacency_fused_supported(int C, int Ci, int T, int V);
+size_t agcn_adjacency_fused_workspace(int C, int Ci);
+int agcn_adjacency_fused_fwd(const float* x, const float* wab, const float* bab, const float* A, const float* PA,
+                             const float* alpha, float* tp_out, float* spart, float* P, float* adj, void* workspace,
+                             size_t workspace_bytes, int N, int C, int Ci, int T, int V, void* stream);
+int agcn_adjacency_fused_bwd_scores(const float* x, const float* wab, const float* bab, const float* dS, float* dtp,
+                                    float* dbpart, void* scratch, float* db, void* workspace, size_t workspace_bytes,
+                                    int N, int C, int Ci, int T, int V, void* stream);
 /* dadj = sum of slots; dS = alpha*P*(dadj - sum_u P*dadj)/(Ci*T); dPA = sum_n dadj; dalpha_part (N*3) or NULL */
 int agcn_adjacency_bwd_softmax(const float* dadj_part, const float* P, const float* alpha, float* dadj, float* dS,
                                float* dPA, float* dalpha_part, int N, int Ci, int T, int V, int nslots, void* stream);

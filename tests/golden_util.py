@@ -106,6 +106,72 @@ def grad_check(g, gold, name, tol):
     err64 = float(np.abs(a - r64).max() / scale)
     return (err32 <= tol) or (err64 <= tol + factor * noise), err32, err64, noise
 
+# ---- parity audit: every golden gradient comparison leaves a record; tests/conftest.py prints one summary line per
+# fixture at the end of the run (so the test log shows HOW each tensor passed, not just that it did) ----
+AUDIT = {}
+
+
+def audit_grads(fixture, named_grads, gold, tol, scalar_tol=None):
+    """Check every (name, gradient) against the fixture with ``grad_check`` and record, per fixture: tensors compared,
+    how many passed the PRIMARY criterion (err32 <= tol, distance to the reference's fp32 run), how many only through
+    the fp64/perturbation band, the worst err32 / err64 / band and their tensor names.
+    Structurally-zero bias gradients are checked absolutely (<= 1e-5) and counted separately.
+    Returns (bad, summary): bad = [(name, err32, err64, band)] of failing tensors."""
+    rec = AUDIT.setdefault(fixture, {'tensors': 0, 'primary': 0, 'band': 0, 'failed': 0, 'zero_bias': 0,
+                                     'worst_err32': (0.0, ''), 'worst_err64': (0.0, ''), 'max_band': (0.0, ''),
+                                     'tol': tol})
+    bad = []
+    for name, g in named_grads:
+        g = np.asarray(g)
+        if is_zero_grad_bias(name):
+            rec['zero_bias'] += 1
+            if float(np.abs(g).max()) >= 1e-5:
+                bad.append((name, float(np.abs(g).max()), None, None))
+                rec['failed'] += 1
+            continue
+        t = scalar_tol if (scalar_tol is not None and g.size == 1) else tol
+        ok, e32, e64, noise = grad_check(g, gold, name, t)
+        rec['tensors'] += 1
+        if e32 <= t:
+            rec['primary'] += 1
+        elif ok:
+            rec['band'] += 1
+        else:
+            rec['failed'] += 1
+            bad.append((name, e32, e64, noise))
+        if e32 > rec['worst_err32'][0]:
+            rec['worst_err32'] = (e32, name)
+        if e64 is not None and e64 > rec['worst_err64'][0]:
+            rec['worst_err64'] = (e64, name)
+        if noise is not None and noise > rec['max_band'][0]:
+            rec['max_band'] = (noise, name)
+    return bad, rec
+
+
+def audit_value(fixture, what, err, tol):
+    """Record a scalar comparison (outputs, logits, dx, layer-wise errors) next to the gradient audit."""
+    rec = AUDIT.setdefault(fixture, {'tensors': 0, 'primary': 0, 'band': 0, 'failed': 0, 'zero_bias': 0,
+                                     'worst_err32': (0.0, ''), 'worst_err64': (0.0, ''), 'max_band': (0.0, ''),
+                                     'tol': tol})
+    rec.setdefault('values', {})[what] = (float(err), float(tol))
+    return err <= tol
+
+
+def audit_lines():
+    out = []
+    for fx, r in AUDIT.items():
+        n = max(1, r['tensors'])
+        line = (f"parity-audit {fx}: grads {r['tensors']} tensors, primary(err32<={r['tol']:g}) {r['primary']} "
+                f"({100.0 * r['primary'] / n:.1f}%), via fp64/perturbation band {r['band']}, failed {r['failed']}, "
+                f"zero-bias(abs) {r['zero_bias']}; worst err32 {r['worst_err32'][0]:.2e} [{r['worst_err32'][1]}], "
+                f"worst err64 {r['worst_err64'][0]:.2e} [{r['worst_err64'][1]}], "
+                f"max band {r['max_band'][0]:.2e} [{r['max_band'][1]}]")
+        if r.get('values'):
+            line += '; ' + ', '.join(f"{k} {e:.2e}(tol {t:g})" for k, (e, t) in r['values'].items())
+        out.append(line)
+    return out
+
+
 AAGCN_UNIT_NAMES = ['au_64_64_s1_v25', 'au_64_128_s2_v25', 'au_3_64_s1_v18', 'au_64_64_s1_v25_plain']
 
 

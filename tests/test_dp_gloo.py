@@ -86,6 +86,64 @@ def test_flat_allreduce_world2(tmp_path):
     assert abs(res[0]['loss_sum'] - losses) < 1e-5
 
 
+def _engine_net():
+    """Several top-level children so that the engine finds a cut for its early (tail) bucket."""
+    torch.manual_seed(0)
+    net = torch.nn.Sequential()
+    net.add_module('l1', torch.nn.Sequential(torch.nn.Conv2d(3, 4, (9, 1), padding=(4, 0)), torch.nn.BatchNorm2d(4),
+                                             torch.nn.ReLU()))
+    net.add_module('l2', torch.nn.Sequential(torch.nn.Conv2d(4, 16, 1), torch.nn.BatchNorm2d(16), torch.nn.ReLU()))
+    net.add_module('l3', torch.nn.Sequential(torch.nn.Conv2d(16, 16, 1), torch.nn.ReLU()))
+    net.add_module('pool', torch.nn.Sequential(torch.nn.AdaptiveAvgPool2d(1), torch.nn.Flatten()))
+    net.add_module('fc', torch.nn.Linear(16, 5))
+    return net
+
+
+def _engine_worker(rank, world, port, out_dir):
+    sys.path.insert(0, ROOT)
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    import agcn_amd  # noqa: F401
+    from agcn_amd import dp
+    from agcn_amd.trainer import TrainEngine
+    dp.init_distributed(backend='gloo')
+    net = _engine_net()
+    eng = TrainEngine(net, world_size=world)
+    assert eng._tail_lo is not None and 0 < eng._tail_lo < len(eng.fp.params)      # an early bucket exists
+    x, y = _batch()
+    idx = dp.shard_indices(x.shape[0], rank, world)
+    for _ in range(2):                               # twice: the views/hooks must survive a step
+        loss = torch.nn.functional.cross_entropy(net(x[idx]), y[idx])
+        eng.backward_and_reduce(loss)
+    assert eng.early_buckets == 2                    # both steps reduced their tail bucket from inside the backward
+    for p, o in zip(eng.fp.params, eng.fp.offsets):
+        assert p.grad.data_ptr() == eng.fp.grad.data_ptr() + 4 * o
+    torch.save({'grad': eng.fp.grad.clone() / world, 'idx': idx, 'tail_lo': eng._tail_lo},
+               os.path.join(out_dir, f'eng{rank}.pt'))
+    torch.distributed.destroy_process_group()
+
+
+def test_engine_bucketed_allreduce_world2(tmp_path):
+    """TrainEngine.backward_and_reduce: tail bucket reduced from the backward hook, head at the end; the result is the
+    average of the shard gradients (per-replica BN), identical on both ranks."""
+    world = 2
+    mp.spawn(_engine_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    res = [torch.load(os.path.join(tmp_path, f'eng{r}.pt')) for r in range(world)]
+    assert torch.equal(res[0]['grad'], res[1]['grad'])
+    sys.path.insert(0, ROOT)
+    import agcn_amd  # noqa: F401
+    from agcn_amd.trainer import TrainEngine
+    x, y = _batch()
+    acc = None
+    for r in range(world):
+        net = _engine_net()
+        eng = TrainEngine(net, world_size=1)
+        for _ in range(2):
+            loss = torch.nn.functional.cross_entropy(net(x[res[r]['idx']]), y[res[r]['idx']])
+            eng.backward_and_reduce(loss)
+        acc = eng.fp.grad.clone() if acc is None else acc + eng.fp.grad
+    assert torch.allclose(res[0]['grad'], acc / world, rtol=1e-5, atol=1e-7)
+
+
 def test_shard_indices_cover_and_pad():
     import agcn_amd  # noqa: F401
     from agcn_amd import dp

@@ -220,6 +220,64 @@ def test_adjacency_fwd_bwd(case):
     assert float((db.double().cpu() - db_ref).abs().max()) / max(1e-30, float(db_ref.abs().max())) < 2e-3
 
 
+# (N, C, Ci, T, V, weight scale): every (TM, NSUB) instantiation, partial last tiles, V = 18, K not a multiple of 16
+ADJ_FUSED_CASES = [(2, 64, 16, 23, 25, 4.0), (2, 64, 32, 12, 25, 6.0), (2, 128, 64, 9, 18, 6.0), (1, 64, 16, 300, 25, 8.0),
+                   (2, 128, 32, 31, 18, 6.0), (2, 256, 64, 75, 25, 8.0), (2, 3, 16, 17, 25, 1.0), (2, 40, 16, 10, 25, 3.0)]
+
+
+@pytest.mark.parametrize('case', ADJ_FUSED_CASES)
+def test_adjacency_fused_fwd_bwd(case):
+    """theta/phi never stored: P/adj straight from x (reference agcn.py:99-102) and the recomputing backward."""
+    from agcn_amd import ops, lib
+    dev = _gpu()
+    N, C, Ci, T, V, scale = case
+    if not ops.adjacency_fused_supported(C, Ci, T, V):
+        pytest.skip("fused adjacency not built for this shape / AGCN_GEMM mode")
+    g = torch.Generator().manual_seed(5 + C + Ci + T)
+    x = rnd(g, N, C, T, V).requires_grad_(True)
+    wab = rnd(g, 6 * Ci, C, scale=scale / np.sqrt(C)).requires_grad_(True)
+    bab = rnd(g, 6 * Ci, scale=0.3).requires_grad_(True)
+    A = rnd(g, 3, V, V, scale=0.2)
+    PA = rnd(g, 3, V, V, scale=0.05)
+    tp = torch.einsum('oc,nctv->notv', wab, x) + bab.view(1, -1, 1, 1)
+    tp.retain_grad()
+    adjs, Ps = [], []
+    for i in range(3):
+        th = tp[:, (2 * i) * Ci:(2 * i + 1) * Ci].permute(0, 3, 1, 2).reshape(N, V, Ci * T)
+        ph = tp[:, (2 * i + 1) * Ci:(2 * i + 2) * Ci].reshape(N, Ci * T, V)
+        p = torch.softmax(torch.matmul(th, ph) / (Ci * T), dim=-2)
+        Ps.append(p)
+        adjs.append(p + A[i] + PA[i])
+    adj_ref = torch.stack(adjs, 1)
+    xg, wg, bg = x.detach().float().to(dev), wab.detach().float().to(dev), bab.detach().float().to(dev)
+    P, adj = ops.adjacency_fused_fwd(xg, wg, bg, A.float().to(dev), PA.float().to(dev))
+    assert rel(P, torch.stack(Ps, 1)) < TOL
+    assert rel(adj, adj_ref) < TOL
+    P2, adj2, tpk = ops.adjacency_fused_fwd(xg, wg, bg, A.float().to(dev), PA.float().to(dev), keep_tp=True)
+    assert torch.equal(P2, P) and torch.equal(adj2, adj)          # the by-product copy does not change the result
+    assert rel(tpk, tp) < TOL
+    # backward of the scores: dS from the reference softmax backward, then the recomputing kernel
+    dadj = rnd(g, N, 3, V, V)
+    adj_ref.backward(dadj)
+    Pd = torch.stack(Ps, 1).detach()
+    dS = Pd * (dadj - (Pd * dadj).sum(2, keepdim=True)) / (Ci * T)
+    L = ops._L()
+    nt = L.agcn_scores_num_tiles(V, T)
+    dtp = torch.empty((N, 6 * Ci, T, V), device=dev)
+    dbpart = torch.empty((N * nt, 6 * Ci), device=dev)
+    db = torch.empty((6 * Ci,), device=dev)
+    scratch = ops._scratch(6 * Ci, xg)
+    nb = L.agcn_adjacency_fused_workspace(C, Ci)
+    ws = ops._ws(nb, xg)
+    lib.check(L.agcn_adjacency_fused_bwd_scores(lib.ptr(xg), lib.ptr(wg), lib.ptr(bg), lib.ptr(dS.float().to(dev)),
+                                                lib.ptr(dtp), lib.ptr(dbpart), scratch.data_ptr(), lib.ptr(db),
+                                                ws.data_ptr(), nb, N, C, Ci, T, V, lib.stream()), 'fused_bwd_scores')
+    gmax = max(1e-30, float(tp.grad.abs().max()))
+    assert float((dtp.double().cpu() - tp.grad).abs().max()) / gmax < 2e-4
+    db_ref = tp.grad.sum((0, 2, 3))
+    assert float((db.double().cpu() - db_ref).abs().max()) / max(1e-30, float(db_ref.abs().max())) < 2e-3
+
+
 BN_CASES = [(2, 64, 23, 25, 0), (2, 64, 23, 25, 1), (3, 128, 11, 25, 2), (2, 256, 7, 25, 2), (2, 64, 17, 18, 1)]
 
 

@@ -14,6 +14,9 @@ from tests import golden_util as gu
 pytestmark = pytest.mark.gpu
 TOL = 1e-4
 GTOL = 2e-4   # gradients: normalised by max|g_ref| per tensor
+PRIMARY_FRAC = 0.9   # at least this share of the gradient tensors of a fixture must pass the primary criterion
+#                      (err32 <= GTOL against the reference's fp32 run); the rest may pass through the measured
+#                      fp64 / ReLU-kink perturbation band (golden_util.grad_check); the audit summary shows which
 
 
 def _gpu():
@@ -55,15 +58,12 @@ def test_unit_golden(name):
     y = unit(x)
     (y * torch.from_numpy(rn).to(dev)).sum().backward()
     _check_loaded()
-    assert gu.rel_err(y.detach().cpu().numpy(), gold['y']) < TOL
+    assert gu.audit_value(name, 'y', gu.rel_err(y.detach().cpu().numpy(), gold['y']), TOL)
     dxs = max(1.0, float(np.abs(gold['dx']).max()))
-    assert float(np.abs(x.grad.cpu().numpy() - gold['dx']).max()) / dxs < GTOL
-    for k, p in unit.named_parameters():
-        if gu.is_zero_grad_bias(k):
-            assert float(p.grad.abs().max()) < 1e-5, k
-            continue
-        ok, e32, e64, noise = gu.grad_check(p.grad.cpu().numpy(), gold, k, GTOL)
-        assert ok, (k, e32, e64, noise)
+    assert gu.audit_value(name, 'dx', float(np.abs(x.grad.cpu().numpy() - gold['dx']).max()) / dxs, GTOL)
+    bad, rec = gu.audit_grads(name, [(k, p.grad.cpu().numpy()) for k, p in unit.named_parameters()], gold, GTOL)
+    assert not bad, bad[:8]
+    assert rec['primary'] >= PRIMARY_FRAC * rec['tensors'], rec
     for k, b in unit.state_dict().items():
         if k.endswith(('running_mean', 'running_var')):
             assert gu.rel_err(b.cpu().numpy(), gold['buf.' + k]) < TOL, k
@@ -92,17 +92,11 @@ def test_model_golden(name):
     loss = torch.nn.functional.cross_entropy(logits, torch.from_numpy(lab).to(dev))
     loss.backward()
     _check_loaded()
-    assert gu.rel_err(logits.detach().cpu().numpy(), gold['logits']) < TOL
-    assert abs(loss.item() - float(gold['loss'])) < TOL * max(1.0, abs(float(gold['loss'])))
-    bad = []
-    for k, p in model.named_parameters():
-        if gu.is_zero_grad_bias(k):
-            assert float(p.grad.abs().max()) < 1e-5, k
-            continue
-        ok, e32, e64, noise = gu.grad_check(p.grad.cpu().numpy(), gold, k, GTOL)
-        if not ok:
-            bad.append((k, e32, e64, noise))
+    assert gu.audit_value(name, 'logits', gu.rel_err(logits.detach().cpu().numpy(), gold['logits']), TOL)
+    assert gu.audit_value(name, 'loss', abs(loss.item() - float(gold['loss'])) / max(1.0, abs(float(gold['loss']))), TOL)
+    bad, rec = gu.audit_grads(name, [(k, p.grad.cpu().numpy()) for k, p in model.named_parameters()], gold, GTOL)
     assert not bad, bad[:8]
+    assert rec['primary'] >= PRIMARY_FRAC * rec['tensors'], rec
 
 
 def test_model_layerwise_vs_oracle_full_size():
@@ -162,6 +156,11 @@ def test_model_layerwise_vs_oracle_full_size():
             e = float((p.grad.double().cpu() - ref).abs().max()) / max(1e-30, float(ref.abs().max()))
             worst[f'l{k}.{kk}'] = e
             assert e < GTOL, (k, kk, e)
+        gu.audit_value('layerwise_m_ntu_b1(masks imposed)', f'l{k}.y', gu.rel_err(y_k.detach().cpu().numpy(),
+                                                                                     yo.detach().numpy()), TOL)
+        gu.audit_value('layerwise_m_ntu_b1(masks imposed)', f'l{k}.dx', e_dx, GTOL)
+    wk = max(worst, key=worst.get)
+    gu.audit_value('layerwise_m_ntu_b1(masks imposed)', f'worst param grad [{wk}]', worst[wk], GTOL)
 
 
 def test_unit_vs_oracle_seeded_batch():
