@@ -91,6 +91,12 @@ size_t agcn_wgrad_chain_workspace(int agg, int N, int M, int C, int V, int T_out
 int agcn_wgrad_chain(int agg, const float* dy, const float* x, const float* adj, void* ws, size_t ws_bytes, int* nslabs,
                      int N, int M, int C, int V, int T_src, int T_out, int stride, hipStream_t s);
 
+// split-bf16 weight gradient of the 9-tap temporal convolution (wgrad9_bf16.hip): slabs [nslabs][9][M][C] at ws
+bool agcn_wgrad9_bf16_supported(int M, int C, int V, int stride);
+size_t agcn_wgrad9_bf16_workspace(int N, int M, int C, int V, int T, int stride);
+int agcn_wgrad9_bf16(const float* dy, const float* x, void* ws, size_t ws_bytes, int* nslabs, int N, int M, int C, int V,
+                     int T, int stride, hipStream_t s);
+
 // GEMM arithmetic of the 9x1 temporal convolutions (forward / backward-data): 3 = bf16x6 (default: fp32-equivalent
 // accuracy, measured), 0 = f32 MFMA, 2 = bf16x3 (~5e-6 per GEMM; does NOT hold the 1e-4 parity bar end to end).
 // Chosen once per process from the environment variable AGCN_GEMM (bf16x6 | f32 | bf16x3).
@@ -118,6 +124,12 @@ static inline int agcn_allow_big_lds_rt(const void* kern, unsigned char* done) {
   if (dev >= 0) __atomic_store_n(&done[dev], (unsigned char)1, __ATOMIC_RELEASE);
   return AGCN_OK;
 }
+
+// Diagnostic only: the contraction launchers note which kernel instantiation they enqueued last ON THIS THREAD, so that
+// a benchmark can name the kernel it actually timed (agcn_last_kernel()).  Never read by any compute path.
+#include <stdio.h>
+inline thread_local char agcn_last_kernel_buf[192] = "";
+#define AGCN_NOTE_KERNEL(...) snprintf(agcn_last_kernel_buf, sizeof(agcn_last_kernel_buf), __VA_ARGS__)
 
 static inline int agcn_check_launch() {
   hipError_t e = hipGetLastError();

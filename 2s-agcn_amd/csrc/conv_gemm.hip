@@ -522,6 +522,7 @@ int launch_cfg(Problem& p, hipStream_t stream) {
   static unsigned char lds_ok[AGCN_MAX_DEVICES] = {};   // per (kernel instantiation, device): the attribute is per device
   if (int e = agcn_allow_big_lds_rt(reinterpret_cast<const void*>(kern), lds_ok)) return e;
   dim3 grid((unsigned)(a.N * g.ntiles * g.nmb));
+  AGCN_NOTE_KERNEL("conv_gemm_kernel<%d, %d, %d, %d, %d, %d, %d, %d, %d>", TAPS, AGG, WM, WN, TM, TN, CK, WB, EPI);
   hipLaunchKernelGGL(kern, grid, dim3(WM * WN * 64), g.smem_bytes, stream, a);
   return agcn_check_launch();
 }
@@ -550,6 +551,13 @@ extern "C" {
 int agcn_conv_tile_frames(int V, int T_out) {
   int tt = 256 / V;
   return tt > T_out ? T_out : tt;
+}
+// diagnostic: kernel instantiation the calling thread's last contraction launch used ("" if none)
+const char* agcn_last_kernel(void) { return agcn_last_kernel_buf; }
+// "bf16x6" | "f32" | "bf16x3": the arithmetic of the channel contractions, fixed per process by AGCN_GEMM
+const char* agcn_gemm_mode(void) {
+  const int m = agcn_gemm_precision();
+  return m == 3 ? "bf16x6" : (m == 0 ? "f32" : "bf16x3");
 }
 int agcn_conv_num_tiles(int V, int T_out) {
   int tt = agcn_conv_tile_frames(V, T_out);

@@ -322,6 +322,7 @@ int launch_bf(BfProblem& p, hipStream_t stream) {
   auto kern = conv_gemm_bf16_kernel<TAPS, NPL, WQ, TM, TN>;
   static unsigned char lds_ok[AGCN_MAX_DEVICES] = {};   // per (kernel instantiation, device): the attribute is per device
   if (int e = agcn_allow_big_lds_rt(reinterpret_cast<const void*>(kern), lds_ok)) return e;
+  AGCN_NOTE_KERNEL("conv_gemm_bf16_kernel<%d, %d, %d, %d, %d>", TAPS, NPL, WQ, TM, TN);
   hipLaunchKernelGGL(kern, dim3((unsigned)(a.N * g.ntiles * g.nmb)), dim3(NT), g.smem_bytes, stream, a);
   return agcn_check_launch();
 }

@@ -375,6 +375,16 @@ int chain_wgrad_and_reduce(int agg, const WgradArgs& a, float* dw, void* ws, siz
   return launch_reduce((const float*)ws, dw, a.wsize, nslabs, a.M, a.C, a.so_m, a.so_t, a.so_c, stream);
 }
 
+// 9-tap weight gradient on the split-bf16 kernel (AGCN_WGRAD9_BF16=0 keeps the exact-f32 MFMA kernel)
+inline bool wgrad9_bf16_enabled() {
+  static int v = -1;
+  if (v < 0) {
+    const char* e = getenv("AGCN_WGRAD9_BF16");
+    v = (e && atoi(e) == 0) ? 0 : 1;
+  }
+  return v == 1;
+}
+
 inline bool chain_wgrad_enabled() {
   static int v = -1;
   if (v < 0) {
@@ -394,8 +404,13 @@ size_t agcn_conv_bwd_weight_workspace(int N, int Cin, int Cout, int T, int V, in
   const int T_out = (T + 2 * pad - taps) / stride + 1;
   const long wsize = (long)Cout * Cin * taps;
   if (taps == 9) {
-    if (Cout % 128 == 0) return ws_wgrad<9, 0, 4, 1, 2, false>(N, Cout, Cin, V, T_out, stride, wsize);
-    return ws_wgrad<9, 0, 2, 2, 2, false>(N, Cout, Cin, V, T_out, stride, wsize);
+    size_t b9 = (Cout % 128 == 0) ? ws_wgrad<9, 0, 4, 1, 2, false>(N, Cout, Cin, V, T_out, stride, wsize)
+                                  : ws_wgrad<9, 0, 2, 2, 2, false>(N, Cout, Cin, V, T_out, stride, wsize);
+    if (agcn_wgrad9_bf16_supported(Cout, Cin, V, stride)) {
+      const size_t t = agcn_wgrad9_bf16_workspace(N, Cout, Cin, V, T, stride);
+      if (t > b9) b9 = t;
+    }
+    return b9;
   }
   size_t b = (Cout % 128 == 0) ? ws_wgrad<1, 0, 4, 2, 1, false>(N, Cout, Cin, V, T_out, stride, wsize)
                               : ws_wgrad<1, 0, 2, 2, 2, true>(N, Cout, Cin, V, T_out, stride, wsize);
@@ -419,6 +434,12 @@ int agcn_conv_bwd_weight(const float* dy, const float* x, float* dw, void* works
   a.so_m = (long)Cin * taps; a.so_t = 1; a.so_c = taps; a.wsize = (long)Cout * Cin * taps;
   hipStream_t s = (hipStream_t)stream;
   if (taps == 9) {
+    if (wgrad9_bf16_enabled() && agcn_wgrad9_bf16_supported(Cout, Cin, V, stride)) {
+      int nslabs = 0;
+      int rc = agcn_wgrad9_bf16(dy, x, workspace, workspace_bytes, &nslabs, N, Cout, Cin, V, T, stride, s);
+      if (rc) return rc;
+      return launch_reduce((const float*)workspace, dw, a.wsize, nslabs, a.M, a.C, a.so_m, a.so_t, a.so_c, s);
+    }
     if (stride == 1) {
       if (Cout % 128 == 0) return launch_wgrad<9, 0, 4, 1, 2, false, 6>(a, dw, workspace, workspace_bytes, s);
       return launch_wgrad<9, 0, 2, 2, 2, false, 6>(a, dw, workspace, workspace_bytes, s);

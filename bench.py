@@ -4,7 +4,8 @@
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
 
 One process per GPU; per-GPU batch fixed at 64 (BASELINE.json configs[1]/[2], weak scaling); gradients are summed by
-ONE RCCL all-reduce of the flat gradient buffer per step.  Rank 0 prints one JSON line.  Inputs are synthetic and
+two RCCL all-reduces of slices of the flat gradient buffer per step (the tail of the model overlapped with the
+backward); with more than one rank BatchNorm statistics are synchronised like the reference's DDP path.  Rank 0 prints one JSON line.  Inputs are synthetic and
 resident in HBM before the timed region.  The roofline object is measured live (HIP events on the launch stream)
 for the dominant kernel; the cpu_baseline object times the CPU oracle (a port of the reference, never the product
 path) on a bounded sample on this box's host cores.
@@ -57,26 +58,60 @@ def randomize_like_training(model, seed):
                 p.fill_(0.5)
 
 
+def csrc_fingerprint():
+    """sha256 over the kernel sources (2s-agcn_amd/csrc/*.hip, *.h): the key the committed PMC traffic file is valid for."""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    for f in sorted(glob.glob(os.path.join(ROOT, '2s-agcn_amd', 'csrc', '*.hip')) +
+                    glob.glob(os.path.join(ROOT, '2s-agcn_amd', 'csrc', '*.h'))):
+        h.update(os.path.basename(f).encode())
+        with open(f, 'rb') as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
+def pmc_traffic(kernel):
+    """HBM bytes per launch of `kernel` from the committed PMC passes (tools/pmc_traffic.sh -> profiles/pmc_traffic.json,
+    FETCH_SIZE / WRITE_SIZE in separate passes, gfx950 x2 read correction).  Counters cannot be collected inside a
+    timed run, so the file carries the fingerprint of the kernel sources it was measured on; a stale file (any kernel
+    source edited since) is refused and the traffic is reported as null."""
+    path = os.path.join(ROOT, 'profiles', 'pmc_traffic.json')
+    try:
+        with open(path) as f:
+            pmc = json.load(f)
+    except (OSError, ValueError):
+        return None, 'no profiles/pmc_traffic.json'
+    meta = pmc.get('_meta', {})
+    if meta.get('csrc_sha') != csrc_fingerprint():
+        return None, f"stale: measured on csrc {meta.get('csrc_sha')}, this build is {csrc_fingerprint()}"
+    key = [k for k in pmc if k.startswith(kernel)]
+    if not key:
+        return None, 'kernel not in the PMC file'
+    return pmc[key[0]]['hbm_bytes'], f"profiles/pmc_traffic.json (csrc {meta.get('csrc_sha')}, commit {meta.get('git_head')})"
+
+
 def dominant_kernel_roofline(device, reps=10):
-    """The kernel family with the largest share of the step (profiles/r01_*_kernel_stats.txt: conv_gemm_bf16_kernel,
-    ~17 % of GPU time over its instantiations): unit_tcn's 9x1 temporal convolution, timed here as the forward at the
-    l9/l10 shape (N'=128, C=Cout=256, T=75, V=25), timed with HIP events on the stream it
-    is launched on.  Algorithmic work per launch: 2*Cout*Cin*9 FLOP per output position x 128*75*25
-    positions = 283.1 GFLOP (fp32-equivalent).
-    Default arithmetic (AGCN_GEMM=bf16x6): every fp32 product is 6 bf16 MFMA products with fp32 accumulation, so the
-    binding ceiling is the dense bf16 matrix rate / 6 = 2500/6 = 416.7 TFLOP/s of fp32-equivalent work.
-    AGCN_GEMM=f32: exact-f32 MFMA, ceiling 157.3 TFLOP/s.
-    `traffic` = HBM bytes per launch from the committed PMC passes (tools/pmc_roofline.py + tools/pmc_parse.py)."""
+    """The kernel family with the largest share of the step (profiles/*_kernel_stats.txt: conv_gemm_bf16_kernel over
+    its instantiations): unit_tcn's 9x1 temporal convolution, timed as the forward at the l9/l10 shape (N'=128,
+    C=Cout=256, T=75, V=25) with HIP events on the stream it is launched on.  Algorithmic work per launch:
+    2*Cout*Cin*9 FLOP per output position x 128*75*25 positions = 283.1 GFLOP (fp32-equivalent) and 491.5 MB.
+    Arithmetic and ceiling follow the mode the library reports (agcn_gemm_mode): bf16x6 = every fp32 product is 6 bf16
+    MFMA products with fp32 accumulation -> ceiling = dense bf16 rate / 6 = 416.7 TFLOP/s fp32-equivalent; f32 =
+    exact-f32 MFMA, 157.3.  `kernel` is what the launch actually enqueued (agcn_last_kernel), `max_rel_err_vs_fp64` is
+    the timed launch's output checked against an fp64 CPU convolution on one sample (fp32-equivalence on THIS box)."""
     import agcn_amd  # noqa: F401
     from agcn_amd import ops
-    mode = os.environ.get('AGCN_GEMM', 'bf16x6')
+    L = ops._L()
+    mode = L.agcn_gemm_mode().decode()
     N, C, T, V = 128, 256, 75, 25
     g = torch.Generator().manual_seed(0)
     x = torch.randn(N, C, T, V, generator=g).to(device)
     w = (torch.randn(C, C, 9, 1, generator=g) / 48.0).to(device)
     b = torch.zeros(C, device=device)
     for _ in range(2):
-        ops.conv_fwd(x, w, b, 1, want_stats=True)
+        y, _ = ops.conv_fwd(x, w, b, 1, want_stats=True)
+    kernel = L.agcn_last_kernel().decode()
     torch.cuda.synchronize()
     s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     s.record()
@@ -85,28 +120,22 @@ def dominant_kernel_roofline(device, reps=10):
     e.record()
     torch.cuda.synchronize()
     ms = s.elapsed_time(e) / reps          # includes the ~3 us weight-pack launch that precedes every call
+    ref = torch.nn.functional.conv2d(x[:1].double().cpu(), w.double().cpu(), b.double().cpu(), padding=(4, 0))
+    err = float((y[:1].double().cpu() - ref).abs().max() / ref.abs().max())
     flops = 2.0 * C * C * 9 * T * V * N
     achieved = flops / (ms * 1e-3) / 1e12
     if mode == 'f32':
-        kernel, peak, note = 'conv_gemm_kernel<9,0,2,4,2,2,8,11,0>', PEAK_FP32_MFMA_TFLOPS, 'f32 MFMA'
+        peak, note = PEAK_FP32_MFMA_TFLOPS, 'exact-f32 MFMA'
     else:
         products = 3 if mode == 'bf16x3' else 6
-        kernel = 'conv_gemm_bf16_kernel<9,%d,2,4,1>' % (2 if mode == 'bf16x3' else 3)
         peak = round(PEAK_BF16_MFMA_TFLOPS / products, 1)
-        note = f'{products} bf16 MFMA products per fp32 product: peak = {PEAK_BF16_MFMA_TFLOPS:.0f}/{products}'
-    traffic = None
-    try:
-        with open(os.path.join(ROOT, 'profiles', 'r01_pmc_traffic.json')) as f:
-            pmc = json.load(f)
-        key = [k for k in pmc if k.startswith(kernel.replace(',', ', '))]
-        if key:
-            traffic = pmc[key[0]]['hbm_bytes']
-    except (OSError, ValueError):
-        pass
-    return {"bound": "mfma", "kernel": kernel + " (unit_tcn 9x1 conv forward, l9-l10 shape)", "arithmetic": note,
-            "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(achieved / peak, 4),
-            "traffic": traffic, "ms_per_launch": round(ms, 4), "flops_per_launch": flops,
-            "algorithmic_bytes_per_launch": 4.0 * 2 * N * C * T * V}
+        note = f'{products} bf16 MFMA products per fp32 product, fp32 accumulate: peak = {PEAK_BF16_MFMA_TFLOPS:.0f}/{products}'
+    traffic, src = pmc_traffic(kernel)
+    return {"bound": "mfma", "kernel": kernel, "what": "unit_tcn 9x1 conv forward, l9-l10 shape (N'=128, C=256, T=75, V=25)",
+            "arithmetic": note, "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
+            "frac": round(achieved / peak, 4), "traffic": traffic, "traffic_source": src,
+            "ms_per_launch": round(ms, 4), "flops_per_launch": flops,
+            "algorithmic_bytes_per_launch": 4.0 * 2 * N * C * T * V, "max_rel_err_vs_fp64": float(f"{err:.3g}")}
 
 
 GCN_LAYER_SHAPES = [  # (name, C, Cout, T) at N'=128, V=25: the distinct unit_gcn shapes of configs[1]
@@ -115,15 +144,21 @@ GCN_LAYER_SHAPES = [  # (name, C, Cout, T) at N'=128, V=25: the distinct unit_gc
 
 
 def unit_gcn_forward_roofline(device, reps=5, Np=128, V=25):
-    """unit_gcn forward alone (reference agcn.py:92-109, train-mode BN), one entry per layer shape, timed with HIP
-    events on the launch stream.  Algorithmic work per SURVEY 8(d): FLOPs = theta/phi + S + aggregate + project
-    (+ down); bytes = read x once + write y once.  Roofline time = max(bytes / 8 TB/s, FLOPs / 157.3 TFLOP/s) - the
-    whole unit computes in exact-f32 MFMA, so the f32 matrix rate is the compute ceiling.  frac = roofline / measured."""
+    """unit_gcn forward alone (reference agcn.py:92-109, train-mode BN, no autograd), one entry per layer shape, timed
+    with HIP events on the launch stream.  Algorithmic work per SURVEY 8(d): FLOPs = theta/phi + S + aggregate +
+    project (+ down); bytes = read x once + write y once.  Two roofline times are given:
+      * `roofline_ms` / `frac`: per-phase-consistent -- every phase priced at the peak of the arithmetic it actually
+        runs in this build (`phases`): bf16x6 split MFMA (2500/6 = 416.7 TFLOP/s fp32-equivalent) for the theta/phi
+        and conv_d projections, exact-f32 MFMA (157.3) for the score reduction, the aggregation chain and the 1x1
+        `down` convolution; roofline = max(bytes / 8 TB/s, sum_phase FLOPs_phase / peak_phase);
+      * `roofline_f32_ms` / `frac_f32`: SURVEY 8(d)'s definition, all FLOPs at the 157.3 TFLOP/s f32 matrix rate."""
     import agcn_amd  # noqa: F401
     from agcn_amd import ops
     from agcn_amd.model.agcn import unit_gcn
     from agcn_amd.graph.ntu_rgb_d import Graph
     A = Graph().A
+    mode = ops._L().agcn_gemm_mode().decode()
+    split_peak = PEAK_FP32_MFMA_TFLOPS if mode == 'f32' else PEAK_BF16_MFMA_TFLOPS / (3 if mode == 'bf16x3' else 6)
     rows = []
     for name, C, Cout, T in GCN_LAYER_SHAPES:
         torch.manual_seed(0)
@@ -143,15 +178,26 @@ def unit_gcn_forward_roofline(device, reps=5, Np=128, V=25):
             torch.cuda.synchronize()
         ms = s.elapsed_time(e) / reps
         Ci = Cout // 4
-        flops = Np * (6 * 2 * C * Ci * T * V + 3 * 2 * V * V * Ci * T + 3 * 2 * C * T * V * V +
-                      3 * 2 * C * Cout * T * V + (2 * C * Cout * T * V if C != Cout else 0))
+        fused_adj = ops.adjacency_fused_supported(C, Ci, T, V)
+        chained = C >= 32 and mode != 'f32'
+        ph = {  # phase: (FLOPs, peak TFLOP/s of the arithmetic it runs in)
+            'theta_phi': (Np * 6 * 2 * C * Ci * T * V, split_peak if fused_adj else PEAK_FP32_MFMA_TFLOPS),
+            'scores': (Np * 3 * 2 * V * V * Ci * T, PEAK_FP32_MFMA_TFLOPS),
+            'aggregate': (Np * 3 * 2 * C * T * V * V, PEAK_FP32_MFMA_TFLOPS),
+            'project': (Np * 3 * 2 * C * Cout * T * V, split_peak if chained else PEAK_FP32_MFMA_TFLOPS),
+            'down': (Np * 2 * C * Cout * T * V if C != Cout else 0, PEAK_FP32_MFMA_TFLOPS)}
+        flops = sum(f for f, _ in ph.values())
         nbytes = 4.0 * Np * (C + Cout) * T * V
-        t_hbm, t_mfma = nbytes / 8e12 * 1e3, flops / (PEAK_FP32_MFMA_TFLOPS * 1e12) * 1e3
-        roof = max(t_hbm, t_mfma)
+        t_hbm = nbytes / 8e12 * 1e3
+        t_phase = sum(f / (pk * 1e12) for f, pk in ph.values()) * 1e3
+        t_f32 = flops / (PEAK_FP32_MFMA_TFLOPS * 1e12) * 1e3
+        roof, roof32 = max(t_hbm, t_phase), max(t_hbm, t_f32)
         rows.append({"layer": name, "shape": [Np, C, Cout, T, V], "ms": round(ms, 4),
-                     "bound": "hbm" if t_hbm > t_mfma else "mfma", "roofline_ms": round(roof, 4),
-                     "frac": round(roof / ms, 4), "GBps": round(nbytes / ms / 1e6, 1),
-                     "TFLOPs": round(flops / ms / 1e9, 2)})
+                     "bound": "hbm" if t_hbm > t_phase else "mfma", "roofline_ms": round(roof, 4),
+                     "frac": round(roof / ms, 4), "roofline_f32_ms": round(roof32, 4),
+                     "frac_f32": round(roof32 / ms, 4), "hbm_ms": round(t_hbm, 4),
+                     "phases": {k: f"{f / 1e9:.1f} GFLOP @ {pk:.1f}" for k, (f, pk) in ph.items() if f},
+                     "GBps": round(nbytes / ms / 1e6, 1), "TFLOPs": round(flops / ms / 1e9, 2)})
     return rows
 
 
@@ -164,40 +210,52 @@ def host_cores():
     return max(1, min(n, int(os.environ.get('AGCN_CPU_THREADS', '16'))))
 
 
-def cpu_baseline(batch=4, budget_s=15.0, max_steps=40):
-    """The CPU oracle (port of reference agcn.py, pinned to reference-generated fixtures) doing the same training step
-    on a bounded sample: training steps of `batch` clips for about `budget_s` seconds after one warm-up step."""
+def cpu_baseline(batches=(1, 8), warmups=2, reps=5):
+    """the CPU oracle (port of reference agcn.py, pinned to reference-generated fixtures, never the
+    product path) doing the full training step (forward, mean CE, backward, clip_grad_norm_ 1.0, SGD momentum 0.9
+    nesterov wd 1e-4) on (B,3,300,25,2) fp32, x ~ N(0,1) seed 0, for B in {1, 8}: 2 warm-ups, median of 5, all host
+    cores of this box.  `value` is the better of the two batch sizes; both are in `sample`."""
     import numpy as np
     from oracle import agcn_oracle as orc
     from agcn_amd.graph.ntu_rgb_d import Graph
     cores = host_cores()
     torch.set_num_threads(cores)
     A = torch.from_numpy(Graph().A.astype(np.float32))
-    sd = orc.with_grad(orc.randomized_state(orc.model_param_shapes(60, 25), 1, stress=1.0))
-    params = [v for k, v in sd.items() if not orc.is_buffer(k)]
-    opt = torch.optim.SGD(params, lr=0.1, momentum=0.9, nesterov=True, weight_decay=1e-4)
-    g = torch.Generator().manual_seed(0)
-    x = torch.randn(batch, 3, 300, 25, 2, generator=g)
-    y = torch.randint(0, 60, (batch,), generator=g)
+    res = {}
+    for batch in batches:
+        sd = orc.with_grad(orc.randomized_state(orc.model_param_shapes(60, 25), 1, stress=1.0))
+        params = [v for k, v in sd.items() if not orc.is_buffer(k)]
+        opt = torch.optim.SGD(params, lr=0.1, momentum=0.9, nesterov=True, weight_decay=1e-4)
+        g = torch.Generator().manual_seed(0)
+        x = torch.randn(batch, 3, 300, 25, 2, generator=g)
+        y = torch.randint(0, 60, (batch,), generator=g)
 
-    def step():
-        loss = torch.nn.functional.cross_entropy(orc.model_forward(x, sd, A, training=True), y)
-        opt.zero_grad()
-        loss.backward()
-        torch.nn.utils.clip_grad_norm_(params, 1.0)
-        opt.step()
-    print(f"[bench] cpu_baseline: warm-up step on {cores} threads ...", file=sys.stderr, flush=True)
-    step()
-    t0 = time.perf_counter()
-    steps = 0
-    while steps < max_steps and (time.perf_counter() - t0) < budget_s:
-        step()
-        steps += 1
-        print(f"[bench] cpu_baseline: step {steps} at {time.perf_counter() - t0:.1f}s", file=sys.stderr, flush=True)
-    dt = time.perf_counter() - t0
-    return {"value": round(batch * steps / dt, 3), "unit": "clips/s", "cores": cores, "kind": "port",
-            "sample": f"{steps} training steps of batch {batch} (fwd+bwd+clip+SGD) after 1 warm-up, fp32, "
-                      f"torch {torch.__version__} CPU ops, {cores} threads"}
+        def step():
+            loss = torch.nn.functional.cross_entropy(orc.model_forward(x, sd, A, training=True), y)
+            opt.zero_grad()
+            loss.backward()
+            torch.nn.utils.clip_grad_norm_(params, 1.0)
+            opt.step()
+        times = []
+        for i in range(warmups + reps):
+            t0 = time.perf_counter()
+            step()
+            dt = time.perf_counter() - t0
+            if i >= warmups:
+                times.append(dt)
+            print(f"[bench] cpu_baseline: B={batch} step {i + 1}/{warmups + reps} {dt:.2f}s", file=sys.stderr, flush=True)
+        times.sort()
+        res[batch] = batch / times[len(times) // 2]
+    try:
+        with open('/proc/cpuinfo') as f:
+            model = [ln.split(':', 1)[1].strip() for ln in f if ln.startswith('model name')][0]
+    except (OSError, IndexError):
+        model = 'unknown CPU'
+    best = max(res, key=res.get)
+    return {"value": round(res[best], 3), "unit": "clips/s", "cores": cores, "kind": "port",
+            "sample": "full training step (fwd, CE, bwd, clip 1.0, SGD nesterov) of the CPU oracle, fp32, median of "
+                      f"{reps} after {warmups} warm-ups, " + ", ".join(f"B={b}: {v:.2f} clips/s" for b, v in res.items()) +
+                      f"; {cores} threads on {model}, torch {torch.__version__}"}
 
 
 def main():
@@ -208,8 +266,11 @@ def main():
     ap.add_argument('--batch', type=int, default=0, help='per-GPU batch (default: the workload\'s, 64 for configs[1])')
     ap.add_argument('--workload', default='ntu_agcn', choices=sorted(WORKLOADS),
                     help='ntu_agcn = BASELINE configs[1]/[2] (the headline); others are the remaining configs')
-    ap.add_argument('--sync-bn', action='store_true', help='synchronised BatchNorm (reference DDP semantics); '
-                    'default per-replica statistics')
+    ap.add_argument('--sync-bn', choices=('auto', 'on', 'off'), default='auto',
+                    help='BatchNorm statistics over the ranks.  auto (default): synchronised whenever more than one rank '
+                         'runs -- the semantics of the reference\'s only multi-process path (DDP + SyncBatchNorm, '
+                         'utils/processor.py:295), so the multi-GPU number pays the per-layer BN collectives the '
+                         'reference pays; off: per-replica statistics (its nn.DataParallel path, :336-343)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-roofline', action='store_true')
     args = ap.parse_args()
@@ -240,7 +301,8 @@ def main():
     model = build_model(args.workload)
     randomize_like_training(model, seed=0)
     model.to(device)
-    if args.sync_bn:
+    sync_bn = world > 1 and args.sync_bn != 'off'
+    if sync_bn:
         from agcn_amd import dp as _dp
         model = _dp.enable_sync_bn(model, world)
     engine = TrainEngine(model, base_lr=0.1, momentum=0.9, nesterov=True, weight_decay=1e-4, max_grad_norm=1.0,
@@ -269,20 +331,27 @@ def main():
         print(f"[bench] timed {args.steps} steps in {dt:.3f}s", file=sys.stderr, flush=True)
 
     if rank == 0:
+        from agcn_amd import lib as _lib
+        gemm_mode = _lib.load().agcn_gemm_mode().decode()
+        dtype_label = "f32" if gemm_mode in ('bf16x6', 'f32') else "bf16x3 (reduced precision: INVALID as a headline)"
         clips = args.batch * world * args.steps
         out = {
             "metric": "skeleton-clips/sec fwd+bwd, NTU (N,3,300,25,2)" if wl[2] == 25 else
                       "skeleton-clips/sec fwd+bwd, Kinetics (N,3,300,18,2)",
             "value": round(clips / dt, 2), "unit": "clips/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "scaling": "weak", "vs_baseline": None, "dtype": dtype_label, "data": "synthetic",
             "config": {"workload": wl[5] + ", full training step (fwd, CE, bwd, grad all-reduce, clip 1.0, "
                                    "SGD nesterov)",
                        "per_gpu_batch": args.batch, "global_batch": args.batch * world,
                        "input": f"(N,3,300,{wl[2]},2)",
-                       "parallelism": f"dp{world}", "bn": "sync" if args.sync_bn else "per-replica",
-                       "tcn_gemm": os.environ.get('AGCN_GEMM', 'bf16x6') +
-                                   " (9x1 conv fwd/bwd-data; bf16x6 = fp32-equivalent split, fp32 accumulate)"},
+                       "parallelism": f"dp{world}", "bn": "sync (reference DDP semantics)" if sync_bn else "per-replica",
+                       "gemm_arithmetic": gemm_mode + (" (every fp32 product = 6 bf16 MFMA products, fp32 accumulate: "
+                                                       "fp32-equivalent, dropped terms < 2^-24 |ab|)"
+                                                       if gemm_mode == 'bf16x6' else
+                                                       " (exact-f32 MFMA)" if gemm_mode == 'f32' else
+                                                       " (3 bf16 products: NOT fp32-equivalent, fails the 1e-4 parity "
+                                                       "bar; diagnostic mode only)")},
             "final_loss": round(final_loss, 5),
         }
         if world == 1 and not args.no_roofline and args.workload == 'ntu_agcn':

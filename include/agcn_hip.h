@@ -13,7 +13,9 @@
  *  - activations are (N, C, T, V) row-major ("NCHW"), N = batch*persons, V <= 32 joints, P = T*V;
  *  - `stream` is a hipStream_t passed as void*; all work is enqueued on it, nothing synchronises the device, the
  *    functions are re-entrant and hold no mutable global state (forward and autograd-backward threads may call
- *    concurrently);
+ *    concurrently).  What the library does keep is set-once and idempotent: the AGCN_* environment switches are read
+ *    on first use and never change afterwards, and the per-(kernel, device) "dynamic LDS limit raised" flags are
+ *    atomics whose lost race only repeats an idempotent hipFuncSetAttribute;
  *  - return value: 0 = ok, AGCN_ERR_* (negative) = argument/shape problem detected on the host before any launch,
  *    positive = hipError_t of a failed launch.  Nothing throws or aborts.
  *  - results are bitwise reproducible run to run (no float atomics; all cross-workgroup sums go through slabs that
@@ -36,6 +38,12 @@ extern "C" {
 /* load-time checks */
 int agcn_version(void);          /* 100 = 0.1.0 */
 const char* agcn_arch(void);     /* "gfx950" */
+
+/* diagnostics (never used by a compute path): the kernel instantiation the calling thread's last contraction launch
+ * enqueued, and the arithmetic mode of the channel contractions ("bf16x6" = fp32-equivalent 6-product bf16 split,
+ * "f32" = exact-f32 MFMA, "bf16x3"), read once per process from the environment variable AGCN_GEMM */
+const char* agcn_last_kernel(void);
+const char* agcn_gemm_mode(void);
 
 /* ---- tile geometry queries (sizes of the partial slabs below) ---------------------------------------------------- */
 int agcn_conv_tile_frames(int V, int T_out);     /* frames per position tile of the contraction kernels (256/V) */

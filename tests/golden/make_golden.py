@@ -92,7 +92,8 @@ def add_unit_sens(out, unit64, xn, rn, seed):
 
 UNIT_CASES = [
     # name, cin, cout, stride, residual, T, V, seed, stress
-    ('u_3_64_s1_v25', 3, 64, 1, False, 16, 25, 101, 1.0),
+    ('u_3_64_s1_v25', 3, 64, 1, False, 16, 25, 111, 1.0),    # seed 101 put a ReLU input within 1e-6 of the kink: its
+    #                                                          whole perturbation band was 1e-2 instead of ~1e-6
     ('u_64_64_s1_v25', 64, 64, 1, True, 16, 25, 102, 1.0),
     ('u_64_64_s1_v25_stress', 64, 64, 1, True, 32, 25, 103, 6.0),
     ('u_64_128_s2_v25', 64, 128, 2, True, 16, 25, 104, 1.0),
@@ -174,6 +175,7 @@ MODEL_CASES = [
     ('m_ntu_b1', 1, 25, 60, 'graph.ntu_rgb_d.Graph', 201, 3.0, 300),
     ('m_ntu_b2', 2, 25, 60, 'graph.ntu_rgb_d.Graph', 202, 3.0, 300),
     ('m_kin_b2_t64', 2, 18, 400, 'graph.kinetics.Graph', 203, 3.0, 64),
+    ('m_kin_b2', 2, 18, 400, 'graph.kinetics.Graph', 204, 3.0, 300),      # BASELINE configs[4] at its full T
 ]
 
 
@@ -281,6 +283,18 @@ if __name__ == '__main__' and len(sys.argv) == 1:
     for case in MODEL_CASES:
         make_model(ref, *case)
     make_train_trace(ref)
+
+
+if __name__ == '__main__' and len(sys.argv) > 2 and sys.argv[1] == 'only':     # regenerate the named fixtures only
+    torch.manual_seed(0)
+    torch.set_num_threads(8)
+    ref = load_reference()
+    for case in UNIT_CASES:
+        if case[0] in sys.argv[2:]:
+            make_unit(ref, *case)
+    for case in MODEL_CASES:
+        if case[0] in sys.argv[2:]:
+            make_model(ref, *case)
 
 
 # ------------------------------------------------------------------------------------------------

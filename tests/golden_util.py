@@ -8,7 +8,7 @@ GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
 UNIT_NAMES = ['u_3_64_s1_v25', 'u_64_64_s1_v25', 'u_64_64_s1_v25_stress', 'u_64_128_s2_v25',
               'u_128_256_s2_v25', 'u_64_64_s1_v18', 'u_64_128_s2_v18_oddT']
-MODEL_NAMES = ['m_ntu_b1', 'm_ntu_b2', 'm_kin_b2_t64']
+MODEL_NAMES = ['m_ntu_b1', 'm_ntu_b2', 'm_kin_b2_t64', 'm_kin_b2']
 
 
 def load(name):
@@ -132,8 +132,16 @@ def audit_grads(fixture, named_grads, gold, tol, scalar_tol=None):
         t = scalar_tol if (scalar_tol is not None and g.size == 1) else tol
         ok, e32, e64, noise = grad_check(g, gold, name, t)
         rec['tensors'] += 1
+        rec.setdefault('err32_all', []).append(e32)
+        # the reference's OWN fp32-vs-fp64 distance for this tensor (no perturbation band mixed in)
+        n32 = ref_noise32(gold, name)
+        if n32 is not None:
+            rec.setdefault('ref_noise32_all', []).append(n32)
+            rec['ref32_within_tol'] = rec.get('ref32_within_tol', 0) + int(n32 <= t)
         if e32 <= t:
             rec['primary'] += 1
+        elif e64 is not None and n32 is not None and e64 <= t + 3.0 * n32:
+            rec['as_ref'] = rec.get('as_ref', 0) + 1      # as close to fp64 as the reference's fp32 run (x3)
         elif ok:
             rec['band'] += 1
         else:
@@ -146,6 +154,16 @@ def audit_grads(fixture, named_grads, gold, tol, scalar_tol=None):
         if noise is not None and noise > rec['max_band'][0]:
             rec['max_band'] = (noise, name)
     return bad, rec
+
+
+def ref_noise32(gold, name):
+    """|reference fp32 gradient - reference fp64 gradient| / max|g|: what the reference itself achieves in fp32."""
+    if ('g64.' + name + '.absmax') not in gold:
+        return None
+    scale = max(float(gold['g.' + name + '.absmax']), 1e-12)
+    key = 'g.' + name if ('g.' + name) in gold else 'g.' + name + '.samples'
+    key64 = 'g64.' + name if ('g64.' + name) in gold else 'g64.' + name + '.samples'
+    return float(np.abs(gold[key].astype(np.float64) - gold[key64].astype(np.float64)).max() / scale)
 
 
 def audit_value(fixture, what, err, tol):
@@ -161,11 +179,21 @@ def audit_lines():
     out = []
     for fx, r in AUDIT.items():
         n = max(1, r['tensors'])
+        if r['tensors'] == 0:
+            out.append(f"parity-audit {fx}: " + ', '.join(f"{k} {e:.2e}(tol {t:g})" for k, (e, t) in
+                                                             r.get('values', {}).items()))
+            continue
         line = (f"parity-audit {fx}: grads {r['tensors']} tensors, primary(err32<={r['tol']:g}) {r['primary']} "
-                f"({100.0 * r['primary'] / n:.1f}%), via fp64/perturbation band {r['band']}, failed {r['failed']}, "
+                f"({100.0 * r['primary'] / n:.1f}%), as close to fp64 as 3x the reference's own fp32 run "
+                f"{r.get('as_ref', 0)}, via ReLU-kink perturbation band {r['band']}, failed {r['failed']}, "
                 f"zero-bias(abs) {r['zero_bias']}; worst err32 {r['worst_err32'][0]:.2e} [{r['worst_err32'][1]}], "
                 f"worst err64 {r['worst_err64'][0]:.2e} [{r['worst_err64'][1]}], "
                 f"max band {r['max_band'][0]:.2e} [{r['max_band'][1]}]")
+        if r.get('err32_all'):
+            line += f"; median err32 {float(np.median(r['err32_all'])):.2e}"
+        if r.get('ref_noise32_all'):
+            line += (f"; the REFERENCE's own fp32-vs-fp64 distance: median {float(np.median(r['ref_noise32_all'])):.2e}, "
+                     f"within {r['tol']:g} for {r.get('ref32_within_tol', 0)}/{len(r['ref_noise32_all'])} tensors")
         if r.get('values'):
             line += '; ' + ', '.join(f"{k} {e:.2e}(tol {t:g})" for k, (e, t) in r['values'].items())
         out.append(line)

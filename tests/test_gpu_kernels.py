@@ -357,3 +357,25 @@ def test_sgd_step_matches_torch():
                                   int(step == 0), lib.ptr(ws), ws.numel() * 4, lib.ptr(norm), lib.stream()), 'sgd')
         assert abs(float(norm[0]) - float(gn)) < 1e-4 * float(gn)
         assert rel(p, p_ref) < 1e-5
+
+
+# N, C(=M), T, V: stride-1 9-tap weight gradient on the split-bf16 kernel (wgrad9_bf16.hip): 64/128-row tiles, ragged
+# last chunk (T % 80 != 0), T not a multiple of 4 (zero padded rows), V = 18
+WGRAD9_CASES = [(2, 64, 23, 25), (2, 128, 85, 25), (3, 64, 300, 18), (2, 256, 75, 25), (1, 128, 150, 25)]
+
+
+@pytest.mark.parametrize('case', WGRAD9_CASES)
+def test_conv9_weight_gradient_split_bf16(case):
+    from agcn_amd import ops
+    dev = _gpu()
+    N, C, T, V = case
+    g = torch.Generator().manual_seed(17 + C + T)
+    x = rnd(g, N, C, T, V)
+    w = rnd(g, C, C, 9, 1, scale=1.0 / np.sqrt(9 * C)).requires_grad_(True)
+    y = F.conv2d(x, w, None, padding=(4, 0))
+    dy = rnd(g, *y.shape)
+    y.backward(dy)
+    dw = ops.conv_bwd_weight(dy.float().to(dev), x.float().to(dev), tuple(w.shape), 1)
+    assert ops._L().agcn_last_kernel().decode().startswith('wgrad9_bf16_kernel') or \
+        ops._L().agcn_gemm_mode().decode() != 'bf16x6'
+    assert rel(dw, w.grad) < TOL

