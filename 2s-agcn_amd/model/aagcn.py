@@ -11,7 +11,8 @@ aggregate+project, BN + down + ReLU) and the temporal unit (9x1 conv, BN, residu
 same gfx950 HIP kernels as AGCN (``ops.UnitGCNFunction`` / ``ops.TCNResidualFunction``).  The three STC attention
 gates between them (bandwidth-bound mean -> tiny conv/fc -> sigmoid -> ``y*s + y`` passes) still use stock
 PyTorch operators; fusing them into one HIP pass is listed in DESIGN.md.  fp32 only (the reference has no bf16 path).
-Not supported: GhostBatchNorm (``gbn_split >= 2``), ``data_norm='ln'``.
+GhostBatchNorm (``gbn_split >= 2``) runs on the same HIP BatchNorm stages (``ghostbatchnorm.py``).  Not supported:
+``data_norm='ln'``.
 """
 import math
 from typing import Optional
@@ -22,11 +23,21 @@ import torch.nn as nn
 
 from .. import ops
 from .agcn import _bn_args, _bn_tick, _require_gpu, bn_init, conv_branch_init, conv_init, import_class
+from .ghostbatchnorm import GhostBatchNorm1d, GhostBatchNorm2d
 
 
-def _no_gbn(gbn_split):
-    if gbn_split is not None and gbn_split >= 2:
-        raise NotImplementedError("agcn_amd.aagcn: GhostBatchNorm (gbn_split >= 2) is not supported")
+def batch_norm_1d(num_channels, gbn_split=None):
+    """reference aagcn.py:45-49"""
+    if gbn_split is None or gbn_split < 2:
+        return nn.BatchNorm1d(num_channels)
+    return GhostBatchNorm1d(num_channels, gbn_split)
+
+
+def batch_norm_2d(num_channels, gbn_split=None):
+    """reference aagcn.py:52-56"""
+    if gbn_split is None or gbn_split < 2:
+        return nn.BatchNorm2d(num_channels)
+    return GhostBatchNorm2d(num_channels, gbn_split)
 
 
 class _Gate(torch.autograd.Function):
@@ -121,13 +132,12 @@ class AdaptiveGCN(nn.Module):
 class TCNUnit(nn.Module):
     def __init__(self, in_channels, out_channels, kernel_size=9, stride=1, pad=True, gbn_split=None):
         super().__init__()
-        _no_gbn(gbn_split)
         if kernel_size not in (1, 9) or not pad:
             raise NotImplementedError("agcn_amd.aagcn.TCNUnit: kernel_size in {1, 9} with padding only")
         padding = (kernel_size - 1) // 2
         self.conv = nn.Conv2d(in_channels, out_channels, kernel_size=(kernel_size, 1), padding=(padding, 0),
                               stride=(stride, 1))
-        self.bn = nn.BatchNorm2d(out_channels)
+        self.bn = batch_norm_2d(out_channels, gbn_split)
         self.stride = stride
         conv_init(self.conv)
         bn_init(self.bn, 1)
@@ -144,7 +154,6 @@ class GCNUnit(nn.Module):
     def __init__(self, in_channels, out_channels, A, coff_embedding=4, num_subset=3, adaptive=AdaptiveGCN,
                  attention=True, gbn_split=None):
         super().__init__()
-        _no_gbn(gbn_split)
         if num_subset != 3:
             raise ValueError("agcn_amd.aagcn.GCNUnit: num_subset must be 3")
         inter_channels = out_channels // coff_embedding
@@ -163,10 +172,10 @@ class GCNUnit(nn.Module):
         else:
             self.attn_s, self.attn_t, self.attn_c = None, None, None
         if in_channels != out_channels:
-            self.down = nn.Sequential(nn.Conv2d(in_channels, out_channels, 1), nn.BatchNorm2d(out_channels))
+            self.down = nn.Sequential(nn.Conv2d(in_channels, out_channels, 1), batch_norm_2d(out_channels, gbn_split))
         else:
             self.down = lambda x: x
-        self.bn = nn.BatchNorm2d(out_channels)
+        self.bn = batch_norm_2d(out_channels, gbn_split)
         self.relu = nn.ReLU(inplace=True)
         for m in self.modules():
             if isinstance(m, nn.Conv2d):
@@ -248,14 +257,13 @@ class BaseModel(nn.Module):
     def __init__(self, num_class=60, num_point=25, num_person=2, in_channels=3, drop_out=0, adaptive=True,
                  gbn_split: Optional[int] = None, fc_cv=False, data_norm='bn'):
         super().__init__()
-        _no_gbn(gbn_split)
         if data_norm != 'bn':
             raise NotImplementedError("agcn_amd.aagcn: data_norm must be 'bn'")
         self.num_class, self.num_person, self.num_point = num_class, num_person, num_point
         self.graph = None
         self.adaptive_fn = AdaptiveGCN if adaptive else NonAdaptiveGCN
         self.data_norm = data_norm
-        self.data_bn = nn.BatchNorm1d(num_person * in_channels * num_point)
+        self.data_bn = batch_norm_1d(num_person * in_channels * num_point, gbn_split)
         bn_init(self.data_bn, 1)
         for k in range(1, 11):
             setattr(self, f'l{k}', None)

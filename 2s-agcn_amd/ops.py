@@ -235,8 +235,15 @@ def adjacency_bwd(dy, wcat, x, tp, P, alpha=None, wab=None, bab=None):
 
 
 class BNState:
-    """Per-BatchNorm forward products kept for the backward."""
-    __slots__ = ("mean", "invstd", "scale", "shift")
+    """Per-BatchNorm forward products kept for the backward.  ``S`` > 1: GhostBatchNorm (reference
+    model/layers/module/ghostbatchnorm.py:77-120) -- the statistics are per virtual sub-batch s = n % S, which is an
+    ordinary BatchNorm over (N/S, S*C, T, V): the HIP stages are simply called with that shape (channel index of a row
+    = (n*C + c) % (S*C) = (n % S)*C + c), the coefficient vectors hold S*C entries and the shared weight/bias are
+    repeated S times; nothing in the kernels changes."""
+    __slots__ = ("mean", "invstd", "scale", "shift", "S")
+
+    def __init__(self):
+        self.S = 1
 
 
 class SyncBN:
@@ -326,6 +333,8 @@ def bn_act_fwd(y1, st1, r=None, st2=None, relu=True, want_bits=False):
     """out = act(scale1*y1 + shift1 + res); res = 0 (r None) | r (st2 None) | scale2*r + shift2.
     want_bits: also return the sign bit mask of ``out`` (int32 words, 32 elements each) for the BatchNorm backward."""
     N, C, T, V = y1.shape
+    if st1.S > 1:                      # GhostBatchNorm: (N, C) rows regrouped as (N/S, S*C)
+        N, C = N // st1.S, C * st1.S
     out = torch.empty_like(y1)
     bits = torch.empty((y1.numel() + 31) // 32, dtype=torch.int32, device=y1.device) if want_bits else None
     mode = 0 if r is None else (1 if st2 is None else 2)
@@ -341,6 +350,11 @@ def bn_bwd(dout, mask, y1, gamma1, st1, y2=None, gamma2=None, st2=None, sync=Non
     (positive elements pass) or the int32 sign bit mask of ``bn_act_fwd(..., want_bits=True)``; None = no ReLU.
     Returns dy1, dgamma1, dbeta1, dy2, dgamma2, dbeta2 (branch-2 entries None without y2)."""
     N, C, T, V = y1.shape
+    S = st1.S
+    if S > 1:                          # GhostBatchNorm: see BNState; gamma repeated S times, dgamma/dbeta folded below
+        N, C = N // S, C * S
+        gamma1 = gamma1.repeat(S)
+        gamma2 = gamma2.repeat(S) if gamma2 is not None else None
     part = _empty((N * C * 3,), y1)
     coef = _empty((6 * C,), y1)
     dy1 = torch.empty_like(y1)
@@ -370,6 +384,10 @@ def bn_bwd(dout, mask, y1, gamma1, st1, y2=None, gamma2=None, st2=None, sync=Non
             _lib.ptr(st2.mean) if st2 else None, _lib.ptr(st2.invstd) if st2 else None, _lib.ptr(coef), _lib.ptr(dy1),
             _lib.ptr(dg1), _lib.ptr(db1), _lib.ptr(dy2), _lib.ptr(dg2), _lib.ptr(db2), N, C, T * V, _lib.stream()),
             "agcn_bn_bwd_apply")
+    if S > 1:                          # the weight / bias are shared by the S virtual sub-batches
+        dg1, db1 = dg1.view(S, -1).sum(0), db1.view(S, -1).sum(0)
+        if dg2 is not None:
+            dg2, db2 = dg2.view(S, -1).sum(0), db2.view(S, -1).sum(0)
     return dy1, dg1, db1, dy2, dg2, db2
 
 
@@ -381,15 +399,37 @@ class _Ctx:
     pass
 
 
-def _bn_coeffs(training, stats, count, bns, sync=None):
+def _bn_coeffs(training, stats, count, bns, sync=None, nsamples=None):
     """Coefficients of the BatchNorm stages of one unit (main [+ down/residual]): ``stats`` / ``bns`` are parallel
     lists of partial-sum slabs and (weight, bias, running_mean, running_var).  Returns ([BNState ...], global count)."""
-    if not training:
-        return [bn_eval_coeffs(*bn) for bn in bns], count
+    S = bns[0][2].numel() // bns[0][0].numel()        # GhostBatchNorm keeps S*C running statistics
+    if not training:                                  # eval: plain BN on the first C running entries (reference
+        out = []                                      # ghostbatchnorm.py:108-117; .eval() has averaged them over S)
+        for w, b, rm, rv in bns:
+            C = w.numel()
+            out.append(bn_eval_coeffs(w, b, rm[:C].contiguous(), rv[:C].contiguous()))
+        return out, count
+    if S > 1:
+        if nsamples is None or nsamples % S:
+            raise RuntimeError(f"agcn_amd: GhostBatchNorm with {S} splits needs a batch (x persons) divisible by {S}")
+        stats = [_ghost_regroup(sp, S, nsamples) for sp in stats]
+        bns = [(w.repeat(S), b.repeat(S), rm, rv) for w, b, rm, rv in bns]
+        count = count // S
     if sync is not None:
         stats = sync_stats(stats, count, sync)
         count = count * sync.world
-    return [bn_train_coeffs(sp, count, *bn) for sp, bn in zip(stats, bns)], count
+    res = [bn_train_coeffs(sp, count, *bn) for sp, bn in zip(stats, bns)]
+    for st in res:
+        st.S = S
+    return res, count
+
+
+def _ghost_regroup(stats_part, S, nsamples):
+    """(N*nt, 2, C) per-(sample, tile) partial sums -> (N/S*nt, 2, S*C): sample n = n'*S + s feeds virtual channel
+    s*C + c of row n' (GhostBatchNorm views (N, C, ...) as (N/S, S*C, ...), ghostbatchnorm.py:98-99)."""
+    slots, two, C = stats_part.shape
+    nt = slots // nsamples
+    return stats_part.view(nsamples // S, S, nt, two, C).permute(0, 2, 3, 1, 4).reshape(nsamples // S * nt, two, S * C)
 
 
 def gcn_forward(c, x, A, PA, wab, bab, wd, bd, bn, down, training, alpha=None, adaptive=True, sync=None,
@@ -419,10 +459,10 @@ def gcn_forward(c, x, A, PA, wab, bab, wd, bd, bn, down, training, alpha=None, a
     dpre = bn2 = None
     if down is not None:
         dpre, st2 = conv_fwd(x, down[0], down[1], want_stats=training)
-        (bn1, bn2), gcount = _bn_coeffs(training, [st, st2], count, [bn, down[2:]], sync)
+        (bn1, bn2), gcount = _bn_coeffs(training, [st, st2], count, [bn, down[2:]], sync, N)
         out, bits = bn_act_fwd(ypre, bn1, dpre, bn2, relu=True, want_bits=True)
     else:
-        (bn1,), gcount = _bn_coeffs(training, [st], count, [bn], sync)
+        (bn1,), gcount = _bn_coeffs(training, [st], count, [bn], sync, N)
         out, bits = bn_act_fwd(ypre, bn1, x, None, relu=True, want_bits=True)
     c.g_sync, c.g_count = sync, gcount
     c.g_bits = bits          # sign bit mask of `out` for the BatchNorm backward (32x less traffic than `out`)
@@ -474,11 +514,11 @@ def tcn_forward(c, g, w, b, bn, stride, res_x, res, relu, training, sync=None):
     count = N * To * V
     rpre = bn2 = None
     if res is None or isinstance(res, str):
-        (bn1,), gcount = _bn_coeffs(training, [st], count, [bn], sync)
+        (bn1,), gcount = _bn_coeffs(training, [st], count, [bn], sync, N)
         out, bits = bn_act_fwd(zpre, bn1, None if res is None else res_x, None, relu=relu, want_bits=True)
     else:
         rpre, st2 = conv_fwd(res_x, res[0], res[1], stride, want_stats=training)
-        (bn1, bn2), gcount = _bn_coeffs(training, [st, st2], count, [bn, res[2:]], sync)
+        (bn1, bn2), gcount = _bn_coeffs(training, [st, st2], count, [bn, res[2:]], sync, N)
         out, bits = bn_act_fwd(zpre, bn1, rpre, bn2, relu=relu, want_bits=True)
     c.t_sync, c.t_count = sync, gcount
     c.t_bits = bits

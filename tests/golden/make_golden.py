@@ -329,18 +329,22 @@ AAGCN_UNIT_CASES = [
     ('au_64_128_s2_v25', 64, 128, 2, True, 16, 25, 402, 3.0, True, True),
     ('au_3_64_s1_v18', 3, 64, 1, False, 16, 18, 403, 1.0, True, True),
     ('au_64_64_s1_v25_plain', 64, 64, 1, True, 16, 25, 404, 1.0, False, False),
+    # GhostBatchNorm (gbn_split = 2, batch of 4 person-samples: two per virtual sub-batch); down + residual BNs included
+    ('au_64_128_s2_v25_gbn2', 64, 128, 2, True, 16, 25, 405, 3.0, True, True, 2, 4),
+    ('au_64_64_s1_v25_gbn2', 64, 64, 1, True, 16, 25, 406, 3.0, True, True, 2, 4),
 ]
 
 
-def make_aagcn_unit(ref, name, cin, cout, stride, residual, t, v, seed, stress, adaptive, attention):
+def make_aagcn_unit(ref, name, cin, cout, stride, residual, t, v, seed, stress, adaptive, attention, gbn=None, n=2):
     A = ref_graph(v)
     fn = ref.AdaptiveGCN if adaptive else ref.NonAdaptiveGCN
-    unit = ref.TCNGCNUnit(cin, cout, A, stride=stride, residual=residual, adaptive=fn, attention=attention)
-    shapes = orc.aagcn_unit_param_shapes('', cin, cout, v, stride, residual, adaptive, attention)
+    kw = dict(stride=stride, residual=residual, adaptive=fn, attention=attention, gbn_split=gbn)
+    unit = ref.TCNGCNUnit(cin, cout, A, **kw)
+    shapes = orc.aagcn_unit_param_shapes('', cin, cout, v, stride, residual, adaptive, attention, gbn)
     assert set(shapes) == set(unit.state_dict().keys()), set(shapes) ^ set(unit.state_dict().keys())
     sd = orc.aagcn_randomized_state(shapes, seed, stress=stress)
     unit.load_state_dict(sd)
-    xn, rn = unit_inputs(cin, cout, stride, t, v, seed)
+    xn, rn = unit_inputs(cin, cout, stride, t, v, seed, n=n)
     out = {}
     unit.eval()
     with torch.no_grad():
@@ -352,7 +356,7 @@ def make_aagcn_unit(ref, name, cin, cout, stride, residual, t, v, seed, stress, 
     out['y'] = y.detach().numpy()
     out['dx'] = x.grad.numpy()
     pack_grads(out, unit.named_parameters())
-    unit64 = ref.TCNGCNUnit(cin, cout, A, stride=stride, residual=residual, adaptive=fn, attention=attention).double()
+    unit64 = ref.TCNGCNUnit(cin, cout, A, **kw).double()
     unit64.load_state_dict({k: v_.double() if v_.is_floating_point() else v_ for k, v_ in sd.items()})
     for m_ in unit64.modules():
         if isinstance(m_, ref.NonAdaptiveGCN):
@@ -368,14 +372,33 @@ def make_aagcn_unit(ref, name, cin, cout, stride, residual, t, v, seed, stress, 
             out['buf.' + k] = b.numpy().copy()
     out['meta'] = np.array([cin, cout, stride, int(residual), t, v, seed, int(adaptive), int(attention)], dtype=np.int64)
     out['meta.stress'] = np.float32(stress)
+    out['meta.gbn'] = np.int64(gbn or 0)
+    out['meta.n'] = np.int64(n)
     np.savez_compressed(os.path.join(HERE, name + '.npz'), **out)
     print(f'{name}: y {out["y"].shape} |y|max {np.abs(out["y"]).max():.3f}')
 
 
-def make_aagcn_model(ref, name='am_ntu_b1_t64', n=1, v=25, num_class=60, seed=501, stress=3.0, t=64):
-    model = ref.Model(num_class=num_class, num_point=v, num_person=2, graph='graph.ntu_rgb_d.Graph',
-                      graph_args=dict(labeling_mode='spatial'))
-    shapes = orc.aagcn_model_param_shapes(num_class, v)
+# backbones of reference aagcn.py:407-474 reachable through Model(model_layers=...) (101-103 end in 64 channels, which
+# Model's 256-wide fc cannot take: they only serve the aagcn_vNN research heads), and a GhostBatchNorm model
+AAGCN_MODEL_CASES = [
+    # name, batch, V, classes, seed, stress, T, model_layers, gbn_split, grad samples per tensor
+    ('am_ntu_b1_t64', 1, 25, 60, 501, 3.0, 64, 10, None, 256),
+    ('am_ntu_l3_t32', 1, 25, 60, 502, 3.0, 32, 3, None, 32),
+    ('am_ntu_l6_t32', 1, 25, 60, 503, 3.0, 32, 6, None, 32),
+    ('am_ntu_l7_t32', 1, 25, 60, 504, 3.0, 32, 7, None, 32),
+    ('am_ntu_l3_gbn2_t32', 2, 25, 60, 505, 3.0, 32, 3, 2, 32),
+]
+
+
+def make_aagcn_model(ref, name='am_ntu_b1_t64', n=1, v=25, num_class=60, seed=501, stress=3.0, t=64, model_layers=10,
+                     gbn=None, nsamp=256):
+    global sample_idx
+    _orig_idx = sample_idx
+    sample_idx = lambda numel, k=64: _orig_idx(numel, min(k, nsamp))     # noqa: E731  (smaller fixtures for variants)
+    mk = dict(num_class=num_class, num_point=v, num_person=2, graph='graph.ntu_rgb_d.Graph',
+              graph_args=dict(labeling_mode='spatial'), model_layers=model_layers, gbn_split=gbn)
+    model = ref.Model(**mk)
+    shapes = orc.aagcn_model_param_shapes(num_class, v, model_layers=model_layers, gbn_split=gbn)
     assert set(shapes) == set(model.state_dict().keys()), set(shapes) ^ set(model.state_dict().keys())
     sd = orc.aagcn_randomized_state(shapes, seed, stress=stress)
     model.load_state_dict(sd)
@@ -393,8 +416,7 @@ def make_aagcn_model(ref, name='am_ntu_b1_t64', n=1, v=25, num_class=60, seed=50
     out['logits'] = logits.detach().numpy()
     out['loss'] = np.float64(loss.item())
     pack_grads(out, model.named_parameters(), full_limit=2000)
-    model64 = ref.Model(num_class=num_class, num_point=v, num_person=2, graph='graph.ntu_rgb_d.Graph',
-                        graph_args=dict(labeling_mode='spatial')).double()
+    model64 = ref.Model(**mk).double()
     model64.load_state_dict({k: v_.double() if v_.is_floating_point() else v_ for k, v_ in sd.items()})
     model64.train()
     l64, _ = model64(torch.from_numpy(xn).double())
@@ -414,13 +436,20 @@ def make_aagcn_model(ref, name='am_ntu_b1_t64', n=1, v=25, num_class=60, seed=50
         out['sens.' + k] = np.float32(v_)
     out['meta'] = np.array([n, v, num_class, seed, t], dtype=np.int64)
     out['meta.stress'] = np.float32(stress)
+    out['meta.layers'] = np.int64(model_layers)
+    out['meta.gbn'] = np.int64(gbn or 0)
     np.savez_compressed(os.path.join(HERE, name + '.npz'), **out)
+    sample_idx = _orig_idx
     print(f'{name}: loss {out["loss"]:.6f}')
 
 
 if __name__ == '__main__' and len(sys.argv) > 1 and sys.argv[1] == 'aagcn':
     torch.manual_seed(0)
     ref_a = load_reference_aagcn()
+    only = sys.argv[2:]
     for case in AAGCN_UNIT_CASES:
-        make_aagcn_unit(ref_a, *case)
-    make_aagcn_model(ref_a)
+        if not only or case[0] in only:
+            make_aagcn_unit(ref_a, *case)
+    for case in AAGCN_MODEL_CASES:
+        if not only or case[0] in only:
+            make_aagcn_model(ref_a, *case)

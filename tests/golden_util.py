@@ -200,7 +200,13 @@ def audit_lines():
     return out
 
 
-AAGCN_UNIT_NAMES = ['au_64_64_s1_v25', 'au_64_128_s2_v25', 'au_3_64_s1_v18', 'au_64_64_s1_v25_plain']
+AAGCN_UNIT_NAMES = ['au_64_64_s1_v25', 'au_64_128_s2_v25', 'au_3_64_s1_v18', 'au_64_64_s1_v25_plain',
+                    'au_64_128_s2_v25_gbn2', 'au_64_64_s1_v25_gbn2']          # *_gbn2: GhostBatchNorm, 2 splits
+AAGCN_MODEL_NAMES = ['am_ntu_b1_t64', 'am_ntu_l3_t32', 'am_ntu_l6_t32', 'am_ntu_l7_t32', 'am_ntu_l3_gbn2_t32']
+
+
+def meta_int(gold, key, default=0):
+    return int(gold[key]) if key in gold else default
 
 
 def is_alias_key(name):

@@ -23,14 +23,15 @@ def test_aagcn_unit_golden(name):
     from agcn_amd.model.aagcn import AdaptiveGCN, NonAdaptiveGCN, TCNGCNUnit
     gold = gu.load(name)
     cin, cout, stride, residual, t, v, seed, adaptive, attention = [int(i) for i in gold['meta']]
+    gbn = gu.meta_int(gold, 'meta.gbn') or None          # GhostBatchNorm fixtures (reference ghostbatchnorm.py)
     A = gu.graph_A(v).numpy()
     unit = TCNGCNUnit(cin, cout, A, stride=stride, residual=bool(residual),
-                      adaptive=AdaptiveGCN if adaptive else NonAdaptiveGCN, attention=bool(attention))
-    shapes = orc.aagcn_unit_param_shapes('', cin, cout, v, stride, bool(residual), bool(adaptive), bool(attention))
+                      adaptive=AdaptiveGCN if adaptive else NonAdaptiveGCN, attention=bool(attention), gbn_split=gbn)
+    shapes = orc.aagcn_unit_param_shapes('', cin, cout, v, stride, bool(residual), bool(adaptive), bool(attention), gbn)
     assert set(shapes) == set(unit.state_dict().keys())
     unit.load_state_dict(orc.aagcn_randomized_state(shapes, seed, stress=float(gold['meta.stress'])))
     unit.to(dev)
-    xn, rn = gu.unit_inputs(cin, cout, stride, t, v, seed)
+    xn, rn = gu.unit_inputs(cin, cout, stride, t, v, seed, n=gu.meta_int(gold, 'meta.n', 2))
     unit.eval()
     with torch.no_grad():
         ye = unit(torch.from_numpy(xn).to(dev))
@@ -53,16 +54,20 @@ def test_aagcn_unit_golden(name):
             assert gu.rel_err(b.cpu().numpy(), gold['buf.' + k]) < TOL, k
 
 
-def test_aagcn_model_golden():
+@pytest.mark.parametrize('name', gu.AAGCN_MODEL_NAMES)
+def test_aagcn_model_golden(name):
+    """Full AAGCN, the 3/6/7-layer backbones (reference aagcn.py:407-428) and a GhostBatchNorm model."""
     dev = _gpu()
     from model.aagcn import Model
-    gold = gu.load('am_ntu_b1_t64')
+    gold = gu.load(name)
     n, v, num_class, seed, t = [int(i) for i in gold['meta']]
+    layers, gbn = gu.meta_int(gold, 'meta.layers', 10), gu.meta_int(gold, 'meta.gbn') or None
     model = Model(num_class=num_class, num_point=v, num_person=2, graph='graph.ntu_rgb_d.Graph',
-                  graph_args=dict(labeling_mode='spatial'))
-    shapes = orc.aagcn_model_param_shapes(num_class, v)
+                  graph_args=dict(labeling_mode='spatial'), model_layers=layers, gbn_split=gbn)
+    shapes = orc.aagcn_model_param_shapes(num_class, v, model_layers=layers, gbn_split=gbn)
     assert set(shapes) == set(model.state_dict().keys())
-    assert sum(p.numel() for p in model.parameters()) == 3781668
+    if layers == 10:
+        assert sum(p.numel() for p in model.parameters()) == 3781668
     model.load_state_dict(orc.aagcn_randomized_state(shapes, seed, stress=float(gold['meta.stress'])))
     model.to(dev)
     xn, lab = gu.model_inputs(n, v, num_class, seed, t)
@@ -75,7 +80,7 @@ def test_aagcn_model_golden():
     logits, _ = model(torch.from_numpy(xn).to(dev))
     loss = torch.nn.functional.cross_entropy(logits, torch.from_numpy(lab).to(dev))
     loss.backward()
-    fx = 'am_ntu_b1_t64'
+    fx = name
     assert gu.audit_value(fx, 'logits', gu.rel_err(logits.detach().cpu().numpy(), gold['logits']), TOL)
     assert gu.audit_value(fx, 'loss', abs(loss.item() - float(gold['loss'])) / max(1.0, abs(float(gold['loss']))), TOL)
     # full-model gradients are ReLU-kink conditioned (see test_gpu_parity.py::test_model_golden): every tensor must
