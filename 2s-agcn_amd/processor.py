@@ -76,6 +76,13 @@ def get_parser():
                         'the reference\'s single-process nn.DataParallel path, processor.py:336-343)')
     p.add_argument('--world-size', type=int, default=1)
     p.add_argument('--max-steps-per-epoch', type=int, default=0, help='0 = whole epoch (synthetic smoke runs)')
+    p.add_argument('--save-score', type=str2bool, default=False,
+                   help='write <work_dir>/score/epoch<N>_<loader>.pkl {sample_name: logits} after an eval '
+                        '(reference processor.py:199-210), the input of ensemble.py')
+    p.add_argument('--device-augment', type=str2bool, default=True,
+                   help='apply the feeder\'s random transforms to whole batches on the GPU (feeders.DeviceAugment) '
+                        'instead of per sample on the host; only feeders that support it (feeders.feeder.Feeder)')
+    p.add_argument('--prefetch-depth', type=int, default=2, help='batches staged ahead through pinned host buffers')
     return p
 
 
@@ -142,6 +149,9 @@ class Processor:
         np.random.seed(arg.seed)
         os.makedirs(os.path.join(arg.work_dir, 'weight'), exist_ok=True)
         self.global_step = 0
+        if str(arg.optimizer).upper() != 'SGD':
+            raise ValueError(f"agcn_amd.Processor: optimizer {arg.optimizer!r} is not built for this path (SGD with "
+                             f"momentum/nesterov only: reference processor.py:395-401); SAM/Adam/LLRD are out of scope")
         self.load_model()
         self.load_data()
         sync_bn = getattr(arg, 'sync_bn', None)
@@ -192,7 +202,8 @@ class Processor:
         if self.rank != 0:
             return None
         sd = {k: v.detach().cpu().clone() for k, v in self.model.state_dict().items()}
-        name = self.arg.model_saved_name or os.path.join(self.arg.work_dir, 'weight', 'agcn')
+        # reference: <work_dir>/weight/<ModelClass>-<epoch>-<global_step>.pt (processor.py:225-231)
+        name = self.arg.model_saved_name or os.path.join(self.arg.work_dir, 'weight', self.arg.model.split('.')[-1])
         path = f'{name}-{epoch}-{int(self.global_step)}.pt'
         os.makedirs(os.path.dirname(path) or '.', exist_ok=True)
         torch.save(sd, path)
@@ -200,79 +211,161 @@ class Processor:
 
     # ---- data -----------------------------------------------------------------------------------------------------
     def load_data(self):
+        """Datasets + per-rank sampling (reference processor.py:479-520 / feeders/loader.py:378-393).  Batches reach the
+        GPU through a pinned double-buffered ring (feeders.DeviceLoader); feeders that can defer their random
+        transforms get them applied batch-wise on the device (feeders.DeviceAugment)."""
+        from .feeders import DeviceAugment
         Feeder = import_class(self.arg.feeder)
-        self.data_loader = {}
+        self.datasets, self.augment = {}, {}
+
+        def build(kwargs, train):
+            kw = dict(kwargs)
+            dev_aug = bool(self.arg.device_augment) and hasattr(Feeder, 'rotation_theta')
+            if dev_aug:
+                kw['device_augment'] = True
+            ds = Feeder(**kw)
+            return ds, (DeviceAugment.from_feeder(ds) if dev_aug else None)
         if self.arg.phase == 'train':
-            ds = Feeder(**self.arg.train_feeder_args)
-            idx = _dp.shard_indices(len(ds), self.rank, self.world)
-            self.data_loader['train'] = torch.utils.data.DataLoader(
-                torch.utils.data.Subset(ds, idx), batch_size=self.arg.batch_size, shuffle=True, drop_last=True,
-                num_workers=self.arg.num_worker, pin_memory=True)
-        ds = Feeder(**(self.arg.test_feeder_args or self.arg.train_feeder_args))
-        idx = _dp.shard_indices(len(ds), self.rank, self.world)
-        self.data_loader['test'] = torch.utils.data.DataLoader(
-            torch.utils.data.Subset(ds, idx), batch_size=self.arg.test_batch_size, shuffle=False, drop_last=False,
-            num_workers=self.arg.num_worker, pin_memory=True)
+            self.datasets['train'], self.augment['train'] = build(self.arg.train_feeder_args, True)
+        self.datasets['test'], self.augment['test'] = build(self.arg.test_feeder_args or self.arg.train_feeder_args, False)
+
+    def _loader(self, name, epoch):
+        """One epoch of device batches for this rank.  Train: DistributedSampler semantics -- every rank shuffles the
+        SAME seeded permutation (seed + epoch, ``set_epoch``), pads it by wrap-around to a multiple of the world size and
+        takes every world-th index.  Test: strided shards in order, the padded tail is dropped again when the scores
+        are gathered (reference processor.py:862-868)."""
+        from .feeders import DeviceLoader
+        ds = self.datasets[name]
+        n = len(ds)
+        if name == 'train':
+            g = torch.Generator().manual_seed(int(self.arg.seed) + int(epoch))
+            order = torch.randperm(n, generator=g).tolist()
+            bs, drop = self.arg.batch_size, True
+        else:
+            order, bs, drop = list(range(n)), self.arg.test_batch_size, False
+        per = (n + self.world - 1) // self.world
+        order = order + order[:per * self.world - n]
+        idx = order[self.rank::self.world]
+        dl = torch.utils.data.DataLoader(torch.utils.data.Subset(ds, idx), batch_size=bs, shuffle=False,
+                                         drop_last=drop, num_workers=self.arg.num_worker)
+        return DeviceLoader(dl, self.device, depth=self.arg.prefetch_depth), idx
 
     # ---- one epoch ------------------------------------------------------------------------------------------------
     def train(self, epoch):
         self.engine.lr = learning_rate(epoch, self.arg.base_lr, self.arg.step, self.arg.warm_up_epoch)
         freeze_pa = self.arg.only_train_part and epoch <= self.arg.only_train_epoch
         self.print_log(f'Training epoch: {epoch + 1}, lr {self.engine.lr:.6f}')
-        t_data = t_net = 0.0
-        losses, t0 = [], time.perf_counter()
-        for step, (data, label, _) in enumerate(self.data_loader['train']):
-            data = data.to(self.device, non_blocking=True)
-            label = label.to(self.device, non_blocking=True)
-            t1 = time.perf_counter()
-            t_data += t1 - t0
-            # reference zeroes the PA gradients while epoch <= only_train_epoch (processor.py:699-702); here they are
-            # zeroed before the fused clip+update, so the clip norm excludes them (the reference clips first)
-            loss = self.engine.train_step(data, label, before_step=self._zero_pa_grads if freeze_pa else None)
+        # the reference's three buckets (processor.py:608, 670, 709, 752, 759-775): waiting for data / the step /
+        # statistics + logging.  The device is synchronised at the bucket borders so the split is real time.
+        timer = dict(dataloader=0.0, model=0.0, statistics=0.0)
+        losses = []
+        loader, _ = self._loader('train', epoch)
+        aug = self.augment.get('train')
+        mark = time.perf_counter()
+
+        def split():
+            nonlocal mark
+            now = time.perf_counter()
+            dt, mark = now - mark, now
+            return dt
+        for step, (data, label, _) in enumerate(loader):
+            data = data.float()
+            if aug is not None:
+                data = aug(data)
+            torch.cuda.current_stream().synchronize()
+            timer['dataloader'] += split()
+            if freeze_pa:
+                loss = self._train_step_frozen_pa(data, label)
+            else:
+                loss = self.engine.train_step(data, label)
             self.global_step += 1
+            torch.cuda.current_stream().synchronize()
+            timer['model'] += split()
             if step % self.arg.log_interval == 0:
                 losses.append(float(loss.detach()))
-                self.print_log(f'\tBatch({step}/{len(self.data_loader["train"])}) done. Loss: {losses[-1]:.4f}  '
+                self.print_log(f'\tBatch({step}/{len(loader)}) done. Loss: {losses[-1]:.4f}  '
                                f'lr:{self.engine.lr:.6f}  grad-norm:{self.engine.grad_norm():.3f}')
-            t0 = time.perf_counter()
-            t_net += t0 - t1
+            timer['statistics'] += split()
             if self.arg.max_steps_per_epoch and step + 1 >= self.arg.max_steps_per_epoch:
                 break
-        torch.cuda.synchronize()
-        tot = max(t_data + t_net, 1e-9)
-        self.print_log(f'\tMean training loss: {np.mean(losses) if losses else float("nan"):.4f}.  '
-                       f'Time consumption: [Data]{100 * t_data / tot:.0f}%, [Network]{100 * t_net / tot:.0f}%')
+        tot = max(sum(timer.values()), 1e-9)
+        self.last_timer = dict(timer)
+        self.print_log(f'\tMean training loss: {np.mean(losses) if losses else float("nan"):.4f}.')
+        self.print_log(f'\tTime consumption  : [Data] {100 * timer["dataloader"] / tot:02.0f}%, '
+                       f'[Network] {100 * timer["model"] / tot:02.0f}%, [Statistics] {100 * timer["statistics"] / tot:02.0f}%')
 
-    def _zero_pa_grads(self):
-        for n, p in self.model.named_parameters():
-            if 'PA' in n and p.grad is not None:
-                p.grad.zero_()
+    def _train_step_frozen_pa(self, data, label):
+        """Reference order while ``epoch <= only_train_epoch`` (processor.py:697-703): backward, clip_grad_norm_ over ALL
+        gradients (PA included), THEN zero the PA gradients, then optimizer.step() -- so PA still takes the weight-decay /
+        momentum part of the SGD update.  The fused clip+SGD kernel runs on the true gradients; the PA slices are then
+        recomputed as the step a zero gradient would have produced."""
+        eng = self.engine
+        slices = []
+        for (n, p), o in zip([(n, p) for n, p in self.model.named_parameters() if p.requires_grad], eng.fp.offsets):
+            if 'PA' in n:
+                slices.append((o, p.numel()))
+        saved = [(eng.fp.flat[o:o + k].clone(), eng.fp.momentum[o:o + k].clone()) for o, k in slices]
+        first = eng.steps_done == 0
+        loss = eng.train_step(data, label)
+        mu, wd, lr = eng.momentum, eng.weight_decay, eng.lr
+        for (o, k), (p0, m0) in zip(slices, saved):
+            d = wd * p0
+            m1 = d.clone() if first else mu * m0 + d
+            upd = d + mu * m1 if eng.nesterov else m1
+            eng.fp.flat[o:o + k] = p0 - lr * upd
+            eng.fp.momentum[o:o + k] = m1
+        return loss
 
-    def eval(self, epoch):
+    def eval(self, epoch, save_score=None, loader_name='test'):
+        """reference processor.py:784-914: eval-mode forward over the shard, scores gathered over the ranks and
+        de-interleaved (:862-868), top-k through the dataset's labels, optional score pickle (:199-210)."""
         self.model.eval()
-        scores, labels, loss_sum, n = [], [], 0.0, 0
+        loader, idx = self._loader(loader_name, epoch)
+        ds = self.datasets[loader_name]
+        scores, loss_sum, seen = [], 0.0, 0
         with torch.no_grad():
-            for data, label, _ in self.data_loader['test']:
-                data = data.to(self.device, non_blocking=True)
-                label = label.to(self.device, non_blocking=True)
-                out = self.model(data)
+            for data, label, _ in loader:
+                out = self.model(data.float())
                 out = out[0] if isinstance(out, tuple) else out
                 loss_sum += float(torch.nn.functional.cross_entropy(out, label, reduction='sum'))
-                n += label.numel()
-                scores.append(out.cpu())
-                labels.append(label.cpu())
-        score, label = torch.cat(scores), torch.cat(labels)
+                seen += label.numel()
+                scores.append(out.float().cpu().numpy())
+        score = np.concatenate(scores) if scores else np.zeros((0, 1), dtype=np.float32)
+        n = len(ds)
+        if self.world > 1:
+            import torch.distributed as dist
+            parts = [None] * self.world
+            dist.all_gather_object(parts, score)
+            full = np.zeros((len(parts[0]) * self.world, score.shape[1]), dtype=score.dtype)
+            for r, val in enumerate(parts):
+                full[r::self.world] = val               # rank r holds samples r, r + W, ... (reference :866-868)
+            score = full[:n]                            # the wrap-around padding of the shards is dropped again
+            loss_sum = _dp.allreduce_scalar(loss_sum, self.world, self.device)
+            seen = _dp.allreduce_scalar(seen, self.world, self.device)
+        labels = np.asarray(ds.label)[:n]
         res = {}
         for k in self.arg.show_topk:
-            hit = (score.topk(min(k, score.shape[1]), dim=1).indices == label[:, None]).any(1).double().sum().item()
-            res[k] = _dp.allreduce_scalar(hit, self.world, self.device)
-        total = _dp.allreduce_scalar(n, self.world, self.device)
-        loss = _dp.allreduce_scalar(loss_sum, self.world, self.device) / max(total, 1)
-        self.print_log(f'\tMean test loss of {int(total)} samples: {loss:.4f}')
-        for k, hit in res.items():
-            self.print_log(f'\tTop{k}: {100.0 * hit / max(total, 1):.2f}%')
-        self.best_acc = max(self.best_acc, res.get(1, 0.0) / max(total, 1))
-        return loss, {k: v / max(total, 1) for k, v in res.items()}
+            kk = min(k, score.shape[1])
+            res[k] = float(np.mean([labels[i] in np.argsort(score[i])[-kk:] for i in range(n)])) if n else 0.0
+        loss = loss_sum / max(seen, 1)
+        self.print_log(f'\tMean {loader_name} loss of {n} samples: {loss:.4f}')
+        for k, acc in res.items():
+            self.print_log(f'\tTop{k}: {100.0 * acc:.2f}%')
+        self.best_acc = max(self.best_acc, res.get(1, 0.0))
+        if (self.arg.save_score if save_score is None else save_score) and self.rank == 0:
+            self.save_scores(epoch, loader_name, score)
+        self.last_score = score
+        return loss, res
+
+    def save_scores(self, epoch, loader_name, score):
+        """{sample_name: logits} pickle, the file ``ensemble.py`` fuses (reference processor.py:199-210)."""
+        names = getattr(self.datasets[loader_name], 'sample_name', None)
+        names = list(names) if names is not None else list(range(len(score)))
+        path = os.path.join(self.arg.work_dir, 'score', f'epoch{epoch + 1}_{loader_name}.pkl')
+        os.makedirs(os.path.dirname(path), exist_ok=True)
+        with open(path, 'wb') as f:
+            pickle.dump(dict(zip(names, score)), f)
+        return path
 
     def start(self):
         if self.arg.phase == 'train':

@@ -292,22 +292,27 @@ def test_training_trace_three_steps():
 
 
 def test_processor_smoke(tmp_path):
-    """The Processor counterpart end to end on synthetic clips: 2 steps of training, checkpoint, reload, eval."""
+    """The Processor counterpart end to end on synthetic clips: 2 steps of training, checkpoint, reload, eval, scores."""
     _gpu()
     import os
+    import pickle
     from agcn_amd.processor import Processor, load_args
     cfg = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'config', 'nturgbd-cross-view',
                        'train_joint.yaml')
-    argv = ['--config', cfg, '--work-dir', str(tmp_path), '--model-saved-name', str(tmp_path / 'weight' / 'm'),
+    argv = ['--config', cfg, '--work-dir', str(tmp_path), '--model-saved-name', '',
             '--batch-size', '4', '--test-batch-size', '4', '--num-epoch', '1', '--max-steps-per-epoch', '2',
-            '--log-interval', '1', '--print-log', 'False']
+            '--log-interval', '1', '--print-log', 'False', '--save-score', 'True']
     arg = load_args(argv)
     arg.train_feeder_args = dict(num_samples=8, window_size=64)
-    arg.test_feeder_args = dict(num_samples=8, window_size=64, seed=1)
+    arg.test_feeder_args = dict(num_samples=6, window_size=64, seed=1)
     p = Processor(arg)
     p.start()
     ckpts = os.listdir(tmp_path / 'weight')
-    assert ckpts and ckpts[0].endswith('-1-2.pt')
+    assert ckpts == ['Model-1-2.pt']                    # <ModelClass>-<epoch>-<global_step>.pt, reference :225-231
+    assert set(p.last_timer) == {'dataloader', 'model', 'statistics'} and p.last_timer['model'] > 0
+    with open(tmp_path / 'score' / 'epoch1_test.pkl', 'rb') as f:
+        sc = pickle.load(f)
+    assert len(sc) == 6 and all(v.shape == (60,) for v in sc.values())
     arg2 = load_args(argv + ['--phase', 'test', '--weights', str(tmp_path / 'weight' / ckpts[0])])
     arg2.train_feeder_args = arg.train_feeder_args
     arg2.test_feeder_args = arg.test_feeder_args
@@ -317,6 +322,54 @@ def test_processor_smoke(tmp_path):
         assert torch.equal(v_.cpu(), p2.model.state_dict()[k].cpu()), k
     loss, acc = p2.eval(0)
     assert np.isfinite(loss) and 0.0 <= acc[1] <= 1.0
+    assert np.allclose(p2.last_score, np.stack([sc[i] for i in range(6)]), atol=1e-5)
+    with pytest.raises(ValueError):
+        Processor(load_args(argv + ['--optimizer', 'Adam']))
+
+
+def test_processor_real_feeder_device_augment_and_frozen_pa(tmp_path):
+    """Reference on-disk format through feeders.feeder.Feeder with the random transforms applied on the GPU, the
+    three-bucket timer, and the reference's clip-then-zero-PA order (processor.py:697-703): while PA is frozen it
+    moves only by the weight-decay / momentum part of the SGD step."""
+    _gpu()
+    import os
+    import pickle
+    from agcn_amd.processor import Processor, load_args
+    rng = np.random.default_rng(0)
+    n = 8
+    data = rng.standard_normal((n, 3, 48, 25, 2)).astype(np.float32)
+    data[:, :, 40:] = 0
+    np.save(tmp_path / 'd.npy', data)
+    with open(tmp_path / 'l.pkl', 'wb') as f:
+        pickle.dump(([f's{i}' for i in range(n)], [int(i) for i in rng.integers(0, 60, n)]), f)
+    cfg = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'config', 'nturgbd-cross-view',
+                       'train_joint.yaml')
+    argv = ['--config', cfg, '--work-dir', str(tmp_path), '--model-saved-name', '', '--feeder', 'feeders.feeder.Feeder',
+            '--batch-size', '4', '--test-batch-size', '4', '--num-epoch', '1', '--log-interval', '1',
+            '--print-log', 'False', '--only-train-part', 'True', '--only-train-epoch', '5', '--weight-decay', '0.01']
+    arg = load_args(argv)
+    fa = dict(data_path=str(tmp_path / 'd.npy'), label_path=str(tmp_path / 'l.pkl'), window_size=32, random_choose=True,
+              random_shift=True, random_move=True)
+    arg.train_feeder_args, arg.test_feeder_args = fa, dict(fa, random_choose=False, random_shift=False, random_move=False)
+    p = Processor(arg)
+    assert p.augment['train'] is not None and p.datasets['train'].device_augment
+    pa0 = p.model.l3.gcn1.PA.detach().clone()
+    w0 = p.model.l3.gcn1.conv_d[0].weight.detach().clone()
+    p.train(0)
+    pa1 = p.model.l3.gcn1.PA.detach()
+    lr, wd = p.engine.lr, 0.01
+    # two steps with zero PA gradient, nesterov momentum 0.9: p1 = p0 - lr*(d0 + .9*d0), d0 = wd*p0; then
+    # d1 = wd*p1, m1 = .9*d0 + d1, p2 = p1 - lr*(d1 + .9*m1)
+    e = pa0.double()
+    d0 = wd * e
+    p1 = e - lr * (d0 + 0.9 * d0)
+    d1 = wd * p1
+    m1 = 0.9 * d0 + d1
+    p2 = p1 - lr * (d1 + 0.9 * m1)
+    assert torch.allclose(pa1.double(), p2, rtol=1e-5, atol=1e-9)
+    assert not torch.equal(p.model.l3.gcn1.conv_d[0].weight.detach(), w0)       # everything else trains
+    loss, acc = p.eval(0)
+    assert np.isfinite(loss)
 
 
 def test_cpu_input_raises():
