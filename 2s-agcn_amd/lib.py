@@ -58,6 +58,9 @@ SIGNATURES = {
     "agcn_bn_bwd": (_I, [_P, _P, _I] + [_P] * 16 + [_I, _I, _I, _P]),
     "agcn_bn_bwd_reduce": (_I, [_P, _P, _I, _P, _P, _P, _I, _I, _I, _P]),
     "agcn_bn_bwd_apply": (_I, [_P, _I, _D, _F, _P, _P, _I] + [_P] * 15 + [_I, _I, _I, _P]),
+    "agcn_stc_row_reduce": (_I, [_P, _P, _P, _P, _I, _P, _P, _F, _F, _I, _I, _I, _I, _P]),
+    "agcn_stc_apply": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
+    "agcn_stc_bwd_apply": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
     "agcn_sgd_step_workspace": (_Z, [ctypes.c_long]),
     "agcn_sgd_step": (_I, [_P, _P, _P, ctypes.c_long, _F, _F, _F, _I, _F, _F, _I, _P, _Z, _P, _P]),
 }

@@ -6,11 +6,13 @@ Same public surface as the reference ``model/architecture/aagcn/aagcn.py``: ``Sp
 ``forward(x) -> (logits, None)``, and the identical state_dict, including the reference's duplicate registration of the
 shared ``conv_d`` ModuleList under ``gcn1.conv_d.*`` and ``gcn1.agcn.conv_d.*`` (:228-233).
 
-What runs where (round 1): the GCN core (theta/phi contraction, adaptive adjacency ``PA + alpha*softmax``, fused
+What runs where: the GCN core (theta/phi contraction, adaptive adjacency ``PA + alpha*softmax``, fused
 aggregate+project, BN + down + ReLU) and the temporal unit (9x1 conv, BN, residual, ReLU) with their backward are the
 same gfx950 HIP kernels as AGCN (``ops.UnitGCNFunction`` / ``ops.TCNResidualFunction``).  The three STC attention
-gates between them (bandwidth-bound mean -> tiny conv/fc -> sigmoid -> ``y*s + y`` passes) still use stock
-PyTorch operators; fusing them into one HIP pass is listed in DESIGN.md.  fp32 only (the reference has no bf16 path).
+gates between them (bandwidth-bound mean -> tiny conv/fc -> sigmoid -> ``y*s + y`` passes) are one autograd
+node (``ops.STCAttentionFunction``): every pass over the (N,C,T,V) activation is a HIP kernel (``csrc/attention.hip``:
+3 reads + 1 write forward, 4 reads + 1 write backward); only the few-KB gate networks (Conv1d C->1, two Linears on
+(N,C,V)/(N,C,T)/(N,C) tensors) are tensor code.
 GhostBatchNorm (``gbn_split >= 2``) runs on the same HIP BatchNorm stages (``ghostbatchnorm.py``).  Not supported:
 ``data_norm='ln'``.
 """
@@ -209,6 +211,12 @@ class GCNUnit(nn.Module):
         _bn_tick(self.bn, self.training)
         if isinstance(self.down, nn.Sequential):
             _bn_tick(self.down[1], self.training)
+        if self.attn_s is not None and self.attn_t is not None and self.attn_c is not None:
+            # the three gates as one autograd node on the HIP reduction / apply passes (ops.STCAttentionFunction); the
+            # attention modules only hold the parameters (their own forward is the stand-alone tensor-op version)
+            s_, t_, c_ = self.attn_s.conv_sa, self.attn_t.conv_ta, self.attn_c
+            return ops.STCAttentionFunction.apply(y, s_.weight, s_.bias, t_.weight, t_.bias, c_.fc1c.weight,
+                                                  c_.fc1c.bias, c_.fc2c.weight, c_.fc2c.bias)
         y = y if self.attn_s is None else self.attn_s(y)
         y = y if self.attn_t is None else self.attn_t(y)
         y = y if self.attn_c is None else self.attn_c(y)

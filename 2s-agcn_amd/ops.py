@@ -234,6 +234,90 @@ def adjacency_bwd(dy, wcat, x, tp, P, alpha=None, wab=None, bab=None):
     return dPA, dtp, dbab, dalpha, dadj
 
 
+def stc_row_reduce(y, g=None, wv=None, wt=None, want_t=False, want_v=False, scale_t=1.0, scale_v=1.0):
+    """One pass over y (N,C,T,V) [times g elementwise]: out_t (N,C,T) = scale_t * sum_v wv[n,v]*y*g and / or
+    out_v (N,C,V) = scale_v * sum_t wt[...,t]*y*g ; wv (N,V), wt (N,T) or (N,C,T); None weights = ones."""
+    N, C, T, V = y.shape
+    out_t = _empty((N, C, T), y) if want_t else None
+    out_v = _empty((N, C, V), y) if want_v else None
+    per_row = int(wt is not None and wt.dim() == 3)
+    _lib.check(_L().agcn_stc_row_reduce(_lib.ptr(y), _lib.ptr(g), _lib.ptr(wv), _lib.ptr(wt), per_row, _lib.ptr(out_t),
+                                        _lib.ptr(out_v), float(scale_t), float(scale_v), N, C, T, V, _lib.stream()),
+               "agcn_stc_row_reduce")
+    return out_t, out_v
+
+
+class STCAttentionFunction(torch.autograd.Function):
+    """AAGCN's three attention gates (reference aagcn.py:59-116 applied at :268-270) as ONE autograd node:
+        y3 = y * (1+se_s[n,v]) * (1+se_t[n,t]) * (1+se_c[n,c])
+    Full-tensor work = HIP passes (forward: two reductions + one apply = 3 reads, 1 write of the activation; backward:
+    one pass over (dout, y), one over y, one apply = 4 reads, 1 write); the gate networks (Conv1d C->1 over joints /
+    frames, two Linears) act on (N,C,V) / (N,C,T) / (N,C) tensors and run as ordinary tensor code, differentiated by
+    autograd on those small tensors inside ``backward``.
+    args: y, sa_w (1,C,Ks), sa_b (1), ta_w (1,C,9), ta_b (1), fc1_w, fc1_b, fc2_w, fc2_b"""
+
+    @staticmethod
+    def _gates(m_s, mv1, sa_w, sa_b, ta_w, ta_b, f1w, f1b, f2w, f2b, a_s=None):
+        """a_s (N,V) from mean_t y; a_t (N,T) from mean_v y1; a_c (N,C) from mean_t(a_t * mean_v y1)."""
+        F = torch.nn.functional
+        if a_s is None:
+            a_s = 1.0 + torch.sigmoid(F.conv1d(m_s, sa_w, sa_b, padding=(sa_w.shape[-1] - 1) // 2)).squeeze(1)
+        if mv1 is None:
+            return a_s, None, None
+        a_t = 1.0 + torch.sigmoid(F.conv1d(mv1, ta_w, ta_b, padding=(ta_w.shape[-1] - 1) // 2)).squeeze(1)
+        m_c = (mv1 * a_t.unsqueeze(1)).mean(-1)
+        a_c = 1.0 + torch.sigmoid(F.linear(F.relu(F.linear(m_c, f1w, f1b)), f2w, f2b))
+        return a_s, a_t, a_c
+
+    @staticmethod
+    def forward(ctx, y, sa_w, sa_b, ta_w, ta_b, f1w, f1b, f2w, f2b):
+        y = y.contiguous()
+        N, C, T, V = y.shape
+        par = (sa_w, sa_b, ta_w, ta_b, f1w, f1b, f2w, f2b)
+        _, m_s = stc_row_reduce(y, want_v=True, scale_v=1.0 / T)                         # mean_t y
+        a_s, _, _ = STCAttentionFunction._gates(m_s, None, *par)
+        a_s = a_s.contiguous()
+        mv1, _ = stc_row_reduce(y, wv=a_s, want_t=True, scale_t=1.0 / V)                 # mean_v y*(1+se_s)
+        _, a_t, a_c = STCAttentionFunction._gates(m_s, mv1, *par, a_s=a_s)
+        a_t, a_c = a_t.contiguous(), a_c.contiguous()
+        out = torch.empty_like(y)
+        _lib.check(_L().agcn_stc_apply(_lib.ptr(y), _lib.ptr(a_s), _lib.ptr(a_t), _lib.ptr(a_c), _lib.ptr(out), N, C, T,
+                                       V, _lib.stream()), "agcn_stc_apply")
+        ctx.save_for_backward(y, m_s, mv1, a_s, a_t, a_c, *par)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        y, m_s, mv1, a_s, a_t, a_c, *par = ctx.saved_tensors
+        dout = dout.contiguous()
+        N, C, T, V = y.shape
+        # one pass over (dout, y): P1[n,c,t] = sum_v a_s dout*y ; P2[n,c,v] = sum_t a_t dout*y
+        P1, P2 = stc_row_reduce(y, g=dout, wv=a_s, wt=a_t, want_t=True, want_v=True)
+        da_c = (P1 * a_t.unsqueeze(1)).sum(-1)
+        da_t = (P1 * a_c.unsqueeze(-1)).sum(1)
+        da_s = (P2 * a_c.unsqueeze(-1)).sum(1)
+        with torch.enable_grad():
+            mv1_ = mv1.detach().requires_grad_(True)
+            p_tc = [p.detach().requires_grad_(True) for p in par[2:]]
+            _, a_t_, a_c_ = STCAttentionFunction._gates(None, mv1_, None, None, *p_tc, a_s=a_s)
+            g_tc = torch.autograd.grad([a_t_, a_c_], [mv1_] + p_tc, [da_t, da_c])
+        dmv1 = (g_tc[0] / V).contiguous()               # mv1 = (1/V) sum_v y*a_s
+        # its two other consumers: y (folded into the apply pass below) and a_s
+        _, R = stc_row_reduce(y, wt=dmv1, want_v=True)
+        da_s = da_s + R.sum(1)
+        with torch.enable_grad():
+            m_s_ = m_s.detach().requires_grad_(True)
+            p_s = [p.detach().requires_grad_(True) for p in par[:2]]
+            a_s_, _, _ = STCAttentionFunction._gates(m_s_, None, *p_s, None, None, None, None, None, None)
+            g_s = torch.autograd.grad(a_s_, [m_s_] + p_s, da_s)
+        dms = (g_s[0] / T).contiguous()                 # m_s = (1/T) sum_t y
+        dy = torch.empty_like(y)
+        _lib.check(_L().agcn_stc_bwd_apply(_lib.ptr(dout), _lib.ptr(a_s), _lib.ptr(a_t), _lib.ptr(a_c), _lib.ptr(dmv1),
+                                           _lib.ptr(dms), _lib.ptr(dy), N, C, T, V, _lib.stream()),
+                   "agcn_stc_bwd_apply")
+        return (dy, g_s[1], g_s[2]) + tuple(g_tc[1:])
+
+
 class BNState:
     """Per-BatchNorm forward products kept for the backward.  ``S`` > 1: GhostBatchNorm (reference
     model/layers/module/ghostbatchnorm.py:77-120) -- the statistics are per virtual sub-batch s = n % S, which is an

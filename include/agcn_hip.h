@@ -168,6 +168,21 @@ int agcn_bn_bwd(const float* dout, const void* mask, int mask_bits, const float*
                 float* part, float* coef, float* dy1, float* dgamma1, float* dbeta1, float* dy2, float* dgamma2,
                 float* dbeta2, int N, int C, int P, void* stream);
 
+/* ---- AAGCN attention gates (config 4) ---------------------------------------------------------------------------------
+ * replaces the full-tensor passes of aagcn.py:59-116, 268-270 (three "mean -> tiny net -> sigmoid -> y*s + y" gates):
+ * agcn_stc_row_reduce: one pass over y (and optionally an elementwise factor g) giving, per (n, c) row,
+ *     out_t[t] = scale_t * sum_v wv[n][v] * y*g   and/or   out_v[v] = scale_v * sum_t wt[n or row][t] * y*g
+ *   (forward: mean_t y, mean_v y*(1+se_s); backward: the two weighted sums of dout*y in one pass, and sum_t dmv*y);
+ * agcn_stc_apply: out = y * a_s[n,v] * a_t[n,t] * a_c[n,c] with a_* = 1 + sigmoid gate, (N,V) / (N,T) / (N,C);
+ * agcn_stc_bwd_apply: dy = dout * a_s a_t a_c + dmv[n,c,t] * a_s[n,v] + dms[n,c,v] (the gradients that reach y through
+ *   the two means folded into the same pass).  The few-KB gate networks stay host tensor code. */
+int agcn_stc_row_reduce(const float* y, const float* g, const float* wv, const float* wt, int wt_per_row, float* out_t,
+                        float* out_v, float scale_t, float scale_v, int N, int C, int T, int V, void* stream);
+int agcn_stc_apply(const float* y, const float* a_s, const float* a_t, const float* a_c, float* out, int N, int C, int T,
+                   int V, void* stream);
+int agcn_stc_bwd_apply(const float* dout, const float* a_s, const float* a_t, const float* a_c, const float* dmv,
+                       const float* dms, float* dy, int N, int C, int T, int V, void* stream);
+
 /* ---- training-step tail on one flat parameter buffer ----------------------------------------------------------------
  * replaces processor.py:698 (clip_grad_norm_(params, 1.0)) + :703 (optimizer.step() of optim.SGD(momentum, nesterov,
  * weight_decay), :395-401).  grad_scale multiplies the gradient first (1/world_size after a SUM all-reduce).

@@ -379,3 +379,37 @@ def test_conv9_weight_gradient_split_bf16(case):
     assert ops._L().agcn_last_kernel().decode().startswith('wgrad9_bf16_kernel') or \
         ops._L().agcn_gemm_mode().decode() != 'bf16x6'
     assert rel(dw, w.grad) < TOL
+
+
+@pytest.mark.parametrize('case', [(2, 64, 23, 25), (3, 128, 30, 18), (2, 64, 300, 25), (2, 32, 7, 25)])
+def test_stc_attention_gates_fwd_bwd(case):
+    """The fused AAGCN attention node (HIP reductions + apply) vs the reference's three gates in fp64 tensor code
+    (aagcn.py:59-116, 268-270): output, dy and all eight parameter gradients."""
+    from agcn_amd import ops
+    dev = _gpu()
+    N, C, T, V = case
+    g = torch.Generator().manual_seed(23 + C + T)
+    ks = V if V % 2 else V - 1
+    y = rnd(g, N, C, T, V).requires_grad_(True)
+    par = [rnd(g, 1, C, ks, scale=0.3 / np.sqrt(C)), rnd(g, 1, scale=0.1), rnd(g, 1, C, 9, scale=0.3 / np.sqrt(C)),
+           rnd(g, 1, scale=0.1), rnd(g, C // 2, C, scale=1 / np.sqrt(C)), rnd(g, C // 2, scale=0.1),
+           rnd(g, C, C // 2, scale=1 / np.sqrt(C)), rnd(g, C, scale=0.1)]
+    par = [p.requires_grad_(True) for p in par]
+    sa_w, sa_b, ta_w, ta_b, f1w, f1b, f2w, f2b = par
+    se = torch.sigmoid(F.conv1d(y.mean(-2), sa_w, sa_b, padding=(ks - 1) // 2))
+    y1 = y * se.unsqueeze(-2) + y
+    se = torch.sigmoid(F.conv1d(y1.mean(-1), ta_w, ta_b, padding=4))
+    y2 = y1 * se.unsqueeze(-1) + y1
+    se = torch.sigmoid(F.linear(F.relu(F.linear(y2.mean(-1).mean(-1), f1w, f1b)), f2w, f2b))
+    ref = y2 * se.unsqueeze(-1).unsqueeze(-1) + y2
+    dout = rnd(g, N, C, T, V)
+    ref.backward(dout)
+    yg = y.detach().float().to(dev).requires_grad_(True)
+    pg = [p.detach().float().to(dev).requires_grad_(True) for p in par]
+    out = ops.STCAttentionFunction.apply(yg, *pg)
+    out.backward(dout.float().to(dev))
+    assert rel(out, ref) < TOL
+    assert rel(yg.grad, y.grad) < TOL
+    for a, b in zip(pg, par):
+        den = max(1e-30, float(b.grad.abs().max()))
+        assert float((a.grad.double().cpu() - b.grad).abs().max()) / den < 2e-4, (tuple(b.shape),)
