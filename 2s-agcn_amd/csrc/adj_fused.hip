@@ -32,6 +32,7 @@ struct AfArgs {
   float* dtp;                  // bwd: (N, 6*Ci, T, V)
   float* dbpart;               // bwd: (N*ntiles, 6*Ci)
   int N, C, Ci, T, V, tt, ntiles, nchunks, nsb;
+  int npl;                     // 3: six split products (bf16x6) ; 1: hi*hi only (bf16)
   int dbg;                     // profiling aid (AGCN_AF_DBG): 1 = skip phase 2, 2 = skip the phase-1 loop
 };
 
@@ -168,7 +169,7 @@ __global__ void __launch_bounds__(NT, (TM * 16 + PD * 8 + 60 <= 128) ? 4 : 2) ad
 #pragma unroll
         for (int pl = 0; pl < 3; ++pl)
           af[pl] = *reinterpret_cast<const bf16x8*>(Ab + pl * A_PLANE + ((h * BM) + tm * 32 + lr) * 16);
-        acc[tm] = sb_mfma6(af[0], af[1], af[2], bf[0], bf[1], bf[2], acc[tm]);
+        acc[tm] = sb_mfma6(af[0], af[1], af[2], bf[0], bf[1], bf[2], acc[tm], a.npl);
       }
       __syncthreads();
     }
@@ -410,6 +411,7 @@ int af_run(int mode, AfArgs a, const float* wab, void* ws, size_t ws_bytes, hipS
   a.tt = g.tt; a.ntiles = g.ntiles; a.nchunks = g.nchunks; a.nsb = g.nsb;
   a.wp = (const unsigned short*)ws;
   { const char* e = getenv("AGCN_AF_DBG"); a.dbg = e ? atoi(e) : 0; }
+  a.npl = agcn_npl();
   if (tm == 3) return af_go<3, 3>(mode, a, wab, ws, g, s);
   if (tm == 2) return af_go<2, 1>(mode, a, wab, ws, g, s);
   return af_go<4, 1>(mode, a, wab, ws, g, s);
@@ -418,7 +420,7 @@ int af_run(int mode, AfArgs a, const float* wab, void* ws, size_t ws_bytes, hipS
 bool af_supported(int C, int Ci, int T, int V) {
   int tm, nsub;
   if (V < 16 || V > 32 || C < 1 || T < 1 || !af_shape(Ci, tm, nsub)) return false;   // tt = 256/V <= 16 frames
-  if (agcn_gemm_precision() != 3) return false;            // AGCN_GEMM=f32 / bf16x3 keep the two-kernel path
+  if (!agcn_chained()) return false;            // AGCN_GEMM=f32 / bf16x3 keep the two-kernel path
   return af_geometry(C, T, V, tm * 32, nsub).smem_bytes <= 160 * 1024;
 }
 

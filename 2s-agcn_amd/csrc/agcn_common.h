@@ -97,9 +97,10 @@ size_t agcn_wgrad9_bf16_workspace(int N, int M, int C, int V, int T, int stride)
 int agcn_wgrad9_bf16(const float* dy, const float* x, void* ws, size_t ws_bytes, int* nslabs, int N, int M, int C, int V,
                      int T, int stride, hipStream_t s);
 
-// GEMM arithmetic of the 9x1 temporal convolutions (forward / backward-data): 3 = bf16x6 (default: fp32-equivalent
-// accuracy, measured), 0 = f32 MFMA, 2 = bf16x3 (~5e-6 per GEMM; does NOT hold the 1e-4 parity bar end to end).
-// Chosen once per process from the environment variable AGCN_GEMM (bf16x6 | f32 | bf16x3).
+// GEMM arithmetic of the channel contractions: 3 = bf16x6 (default: fp32-equivalent accuracy, measured), 0 = f32 MFMA,
+// 2 = bf16x3 (~5e-6 per GEMM; does NOT hold the 1e-4 parity bar end to end), 1 = bf16 (plain bf16 MFMA operands, ONE
+// product per fp32 product, fp32 accumulate and fp32 storage: BASELINE configs[3], ~2^-9 relative per product).
+// Chosen once per process from the environment variable AGCN_GEMM (bf16x6 | f32 | bf16x3 | bf16).
 static inline int agcn_gemm_precision() {
   static int mode = -1;
   if (mode < 0) {
@@ -107,9 +108,13 @@ static inline int agcn_gemm_precision() {
     mode = 3;
     if (e && !strcmp(e, "f32")) mode = 0;
     else if (e && !strcmp(e, "bf16x3")) mode = 2;
+    else if (e && !strcmp(e, "bf16")) mode = 1;
   }
   return mode;
 }
+// the register-chained / split-plane kernel family serves bf16x6 (3 planes, 6 products) and bf16 (hi plane, 1 product)
+static inline bool agcn_chained() { const int m = agcn_gemm_precision(); return m == 3 || m == 1; }
+static inline int agcn_npl() { return agcn_gemm_precision() == 1 ? 1 : 3; }
 
 // Raise a kernel's dynamic-LDS limit to 160 KB on the CURRENT device, once per (kernel, device).  hipFuncSetAttribute
 // is per device, and forward / autograd-backward threads may reach a first launch together: the flags are atomics and

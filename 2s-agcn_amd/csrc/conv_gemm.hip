@@ -557,7 +557,7 @@ const char* agcn_last_kernel(void) { return agcn_last_kernel_buf; }
 // "bf16x6" | "f32" | "bf16x3": the arithmetic of the channel contractions, fixed per process by AGCN_GEMM
 const char* agcn_gemm_mode(void) {
   const int m = agcn_gemm_precision();
-  return m == 3 ? "bf16x6" : (m == 0 ? "f32" : "bf16x3");
+  return m == 3 ? "bf16x6" : (m == 0 ? "f32" : (m == 1 ? "bf16" : "bf16x3"));
 }
 int agcn_conv_num_tiles(int V, int T_out) {
   int tt = agcn_conv_tile_frames(V, T_out);
@@ -566,7 +566,7 @@ int agcn_conv_num_tiles(int V, int T_out) {
 // slots per sample of the (sum, sumsq) partials agcn_conv_fwd writes for these sizes (depends on the kernel picked)
 int agcn_conv_stats_tiles(int Cin, int Cout, int T_out, int V, int taps, int stride) {
   (void)Cin; (void)stride;
-  if (taps == 9 && agcn_gemm_precision() == 3 && Cout % 128 != 0 && agcn_bf16_conv_wide(taps, Cout)) {
+  if (taps == 9 && agcn_chained() && Cout % 128 != 0 && agcn_bf16_conv_wide(taps, Cout)) {
     int tt = 512 / V;
     if (tt > T_out) tt = T_out;
     return (T_out + tt - 1) / tt;
@@ -574,7 +574,7 @@ int agcn_conv_stats_tiles(int Cin, int Cout, int T_out, int V, int taps, int str
   return agcn_conv_num_tiles(V, T_out);
 }
 int agcn_dadj_num_slots(int C, int V, int T) {
-  if (agcn_gemm_precision() == 3 && agcn_gcn_dadj_chain_supported(C, V)) return agcn_gcn_dadj_chain_slots(C, T);
+  if (agcn_chained() && agcn_gcn_dadj_chain_supported(C, V)) return agcn_gcn_dadj_chain_slots(C, T);
   int tt = 128 / V;
   if (tt > T) tt = T;
   int ntiles = (T + tt - 1) / tt;
@@ -613,7 +613,7 @@ size_t agcn_gcn_workspace(int C, int Cout, int T, int V) {
 
 // slots per sample of the (sum, sumsq) partials agcn_gcn_aggregate_project_fwd writes for these sizes
 int agcn_gcn_stats_tiles(int C, int Cout, int T, int V) {
-  if (agcn_gemm_precision() == 3 && C >= 32 && agcn_gcn_chain_supported(Cout, C, V)) return agcn_gcn_chain_tiles(T);
+  if (agcn_chained() && C >= 32 && agcn_gcn_chain_supported(Cout, C, V)) return agcn_gcn_chain_tiles(T);
   return agcn_conv_num_tiles(V, T);
 }
 
@@ -655,9 +655,9 @@ int agcn_conv_bwd_data(const float* dy, const float* w, float* dx, int accumulat
     return agcn_bf16_conv9_bwd_data(dy, w, dx, accumulate, add1, mask1, add2, mask2, workspace, workspace_bytes, N, Cin,
                                     Cout, T, V, stride, agcn_gemm_precision(), (hipStream_t)stream);
   // 1x1 backward-data: measured 10-17% faster on the split-bf16 kernel; the 1x1 forward (store-bound) is not
-  if (taps == 1 && stride == 1 && agcn_gemm_precision() == 3 && Cin >= 64 && Cout >= 32)
+  if (taps == 1 && stride == 1 && agcn_chained() && Cin >= 64 && Cout >= 32)
     return agcn_bf16_conv1_bwd_data(dy, w, dx, accumulate, add1, mask1, add2, mask2, workspace, workspace_bytes, N, Cin,
-                                    Cout, T, V, 3, (hipStream_t)stream);
+                                    Cout, T, V, agcn_gemm_precision(), (hipStream_t)stream);
   Problem p = {};
   ConvGemmArgs& a = p.a;
   a.in = dy; a.out = dx; a.accumulate = accumulate;
@@ -705,7 +705,7 @@ int agcn_gcn_aggregate_project_fwd(const float* x, const float* adj, const float
   if (!x || !adj || !wcat || !y || !workspace || N <= 0 || C <= 0 || Cout <= 0 || T <= 0 || V <= 0 || V > 32)
     return AGCN_ERR_ARG;
   // (the 3-channel first layer's forward stays on the f32 kernel: measured 193 us against 260 us chained)
-  if (agcn_gemm_precision() == 3 && C >= 32 && agcn_gcn_chain_supported(Cout, C, V))
+  if (agcn_chained() && C >= 32 && agcn_gcn_chain_supported(Cout, C, V))
     return agcn_gcn_chain(0, x, adj, wcat, bias, y, stats_part, 0, nullptr, nullptr, nullptr, nullptr, 0, nullptr, nullptr,
                           0, workspace, workspace_bytes, N, C, Cout, T, V, (hipStream_t)stream);
   Problem p = {};
@@ -725,7 +725,7 @@ int agcn_gcn_aggregate_project_bwd_data(const float* dy, const float* adj, const
                                         int N, int C, int Cout, int T, int V, void* stream) {
   if (!dy || !adj || !wcat || !dx || !workspace || N <= 0 || C <= 0 || Cout <= 0 || T <= 0 || V <= 0 || V > 32)
     return AGCN_ERR_ARG;
-  if (agcn_gemm_precision() == 3 && agcn_gcn_chain_supported(C, Cout, V))
+  if (agcn_chained() && agcn_gcn_chain_supported(C, Cout, V))
     return agcn_gcn_chain(1, dy, adj, wcat, nullptr, dx, nullptr, accumulate, add1, mask1, add2, mask2, mask_bits,
                           nullptr, nullptr, 0, workspace, workspace_bytes, N, C, Cout, T, V, (hipStream_t)stream);
   Problem p = {};
@@ -743,7 +743,7 @@ int agcn_gcn_aggregate_project_bwd_data(const float* dy, const float* adj, const
 // w2 (K2, C) row-major (the stacked conv_a/conv_b weights).  Only on the chained (bf16x6) path: check
 // agcn_gcn_bwd_data_fused_supported first.
 int agcn_gcn_bwd_data_fused_supported(int C, int Cout, int V) {
-  return agcn_gemm_precision() == 3 && agcn_gcn_chain_supported(C, Cout, V) ? 1 : 0;
+  return agcn_chained() && agcn_gcn_chain_supported(C, Cout, V) ? 1 : 0;
 }
 int agcn_gcn_aggregate_project_bwd_data_fused(const float* dy, const float* adj, const float* wcat, const float* dtp,
                                               const float* w2, int K2, float* dx, int accumulate, const float* add1,
@@ -764,7 +764,7 @@ int agcn_gcn_dadj(const float* dy, const float* wcat, const float* x, float* dad
                   size_t workspace_bytes, int N, int C, int Cout, int T, int V, void* stream) {
   if (!dy || !wcat || !x || !dadj_part || !workspace || N <= 0 || C <= 0 || Cout <= 0 || T <= 0 || V <= 0 || V > 32)
     return AGCN_ERR_ARG;
-  if (agcn_gemm_precision() == 3 && agcn_gcn_dadj_chain_supported(C, V))
+  if (agcn_chained() && agcn_gcn_dadj_chain_supported(C, V))
     return agcn_gcn_dadj_chain(dy, wcat, x, dadj_part, workspace, workspace_bytes, N, C, Cout, T, V, (hipStream_t)stream);
   if (C >= 64 && C % 64 != 0) return AGCN_ERR_UNSUPPORTED;
   Problem p = {};

@@ -192,7 +192,7 @@ __global__ void __launch_bounds__(NT, (TAPS == 1 && TM == 2) ? 4 : 2) conv_gemm_
       }
       if (rr < qlen && r < WL) {
         *reinterpret_cast<u32x4*>(Bb + ((0 * 2 + hb) * WLR + r) * 16) = ph;
-        *reinterpret_cast<u32x4*>(Bb + ((1 * 2 + hb) * WLR + r) * 16) = pm;
+        if (NPL >= 2) *reinterpret_cast<u32x4*>(Bb + ((1 * 2 + hb) * WLR + r) * 16) = pm;
         if (NPL == 3) *reinterpret_cast<u32x4*>(Bb + ((2 * 2 + hb) * WLR + r) * 16) = pl;
       }
     }
@@ -223,12 +223,14 @@ __global__ void __launch_bounds__(NT, (TAPS == 1 && TM == 2) ? 4 : 2) conv_gemm_
         for (int tn = 0; tn < TN; ++tn) {
           // smallest products first
           if (NPL == 3) {
-            acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[2][tm], bf[0][tn], acc[tm][tn], 0, 0, 0);
-            acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0][tm], bf[2][tn], acc[tm][tn], 0, 0, 0);
-            acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1][tm], bf[1][tn], acc[tm][tn], 0, 0, 0);
+            acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[NPL - 1][tm], bf[0][tn], acc[tm][tn], 0, 0, 0);
+            acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0][tm], bf[NPL - 1][tn], acc[tm][tn], 0, 0, 0);
+            acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[NPL >= 2 ? 1 : 0][tm], bf[NPL >= 2 ? 1 : 0][tn], acc[tm][tn], 0, 0, 0);
           }
-          acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1][tm], bf[0][tn], acc[tm][tn], 0, 0, 0);
-          acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0][tm], bf[1][tn], acc[tm][tn], 0, 0, 0);
+          if (NPL >= 2) {
+            acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[NPL >= 2 ? 1 : 0][tm], bf[0][tn], acc[tm][tn], 0, 0, 0);
+            acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0][tm], bf[NPL >= 2 ? 1 : 0][tn], acc[tm][tn], 0, 0, 0);
+          }
           acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0][tm], bf[0][tn], acc[tm][tn], 0, 0, 0);
         }
     }
@@ -332,9 +334,13 @@ template <int TAPS, int WQ>
 int launch_npl(BfProblem& p, int npl, hipStream_t s) {
   const bool fits128 = bf_geometry<TAPS, 128>(p.a.V, p.a.T_out, p.a.src_stride, p.a.M, p.a.Kinner).smem_bytes <=
                        160 * 1024;
-  if (p.a.M % 128 == 0 && fits128)
+  if (p.a.M % 128 == 0 && fits128) {
+    if (npl == 1) return launch_bf<TAPS, 1, WQ, 4>(p, s);
     return npl == 2 ? launch_bf<TAPS, 2, WQ, 4>(p, s) : launch_bf<TAPS, 3, WQ, 4>(p, s);
+  }
   if (agcn_bf16_conv_wide(TAPS, p.a.M) && npl == 3) return launch_bf<TAPS, 3, 3, 2, 2>(p, s);
+  if (agcn_bf16_conv_wide(TAPS, p.a.M) && npl == 1) return launch_bf<TAPS, 1, 3, 2, 2>(p, s);
+  if (npl == 1) return launch_bf<TAPS, 1, WQ, 2>(p, s);
   return npl == 2 ? launch_bf<TAPS, 2, WQ, 2>(p, s) : launch_bf<TAPS, 3, WQ, 2>(p, s);
 }
 

@@ -391,7 +391,7 @@ inline bool chain_wgrad_enabled() {
     const char* e = getenv("AGCN_WGRAD_BF16");
     v = (e && atoi(e) == 0) ? 0 : 1;
   }
-  return v == 1 && agcn_gemm_precision() == 3;
+  return v == 1 && agcn_chained();
 }
 
 }  // namespace

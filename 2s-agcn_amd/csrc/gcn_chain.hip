@@ -44,6 +44,7 @@ struct ChainArgs {
   int K2, ncb2;                // its channels and 32-channel blocks (0: none)
   int XP;                      // pitch (floats) of an x chunk row in LDS (odd)
   int off_bias;                // byte offset of the bias row in LDS
+  int npl;                     // 3: six split products (bf16x6) ; 1: hi*hi only (bf16)
 };
 
 struct ChainPackArgs {
@@ -276,12 +277,14 @@ __global__ void __launch_bounds__(NW * 64, 2) gcn_chain_kernel(const ChainArgs a
           const bf16x8 a0 = *reinterpret_cast<const bf16x8*>(ab + ((0 * 2 + hf) * TM + tm) * 1024);
           const bf16x8 a1 = *reinterpret_cast<const bf16x8*>(ab + ((1 * 2 + hf) * TM + tm) * 1024);
           const bf16x8 a2 = *reinterpret_cast<const bf16x8*>(ab + ((2 * 2 + hf) * TM + tm) * 1024);
-          // smallest products first
-          acc[tm] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, b0, acc[tm], 0, 0, 0);
-          acc[tm] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b2, acc[tm], 0, 0, 0);
-          acc[tm] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b1, acc[tm], 0, 0, 0);
-          acc[tm] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b0, acc[tm], 0, 0, 0);
-          acc[tm] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b1, acc[tm], 0, 0, 0);
+          // smallest products first; npl == 1 (AGCN_GEMM=bf16): the hi*hi product only
+          if (a.npl == 3) {
+            acc[tm] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, b0, acc[tm], 0, 0, 0);
+            acc[tm] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b2, acc[tm], 0, 0, 0);
+            acc[tm] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b1, acc[tm], 0, 0, 0);
+            acc[tm] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b0, acc[tm], 0, 0, 0);
+            acc[tm] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b1, acc[tm], 0, 0, 0);
+          }
           acc[tm] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b0, acc[tm], 0, 0, 0);
         }
       }
@@ -465,6 +468,7 @@ struct DadjArgs {
   float* dpart;                // (N, 3, nslots, V, V)
   int N, C, Cout, T, V;
   int ntiles, nkc, nmb, nslots, gpc;   // gpc = row blocks per subset (C / BM)
+  int npl;                     // 3: six split products (bf16x6) ; 1: hi*hi only (bf16)
 };
 
 struct DadjPackArgs {
@@ -619,11 +623,13 @@ __global__ void __launch_bounds__(NW * 64, 2) gcn_dadj_chain_kernel(const DadjAr
           const bf16x8 a0 = *reinterpret_cast<const bf16x8*>(ab + ((0 * 2 + ks) * TM + tm) * 1024);
           const bf16x8 a1 = *reinterpret_cast<const bf16x8*>(ab + ((1 * 2 + ks) * TM + tm) * 1024);
           const bf16x8 a2 = *reinterpret_cast<const bf16x8*>(ab + ((2 * 2 + ks) * TM + tm) * 1024);
-          acc[tm] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, b[0], acc[tm], 0, 0, 0);
-          acc[tm] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b[2], acc[tm], 0, 0, 0);
-          acc[tm] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b[1], acc[tm], 0, 0, 0);
-          acc[tm] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b[0], acc[tm], 0, 0, 0);
-          acc[tm] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b[1], acc[tm], 0, 0, 0);
+          if (a.npl == 3) {
+            acc[tm] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, b[0], acc[tm], 0, 0, 0);
+            acc[tm] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b[2], acc[tm], 0, 0, 0);
+            acc[tm] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b[1], acc[tm], 0, 0, 0);
+            acc[tm] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b[0], acc[tm], 0, 0, 0);
+            acc[tm] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b[1], acc[tm], 0, 0, 0);
+          }
           acc[tm] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b[0], acc[tm], 0, 0, 0);
         }
       }
@@ -729,6 +735,7 @@ int agcn_gcn_chain(int mode, const float* in, const float* adj, const float* wca
                    const float* mask2, int mask_bits, const float* in2, const float* w2, int K2, void* ws, size_t ws_bytes,
                    int N, int C, int Cout, int T, int V, hipStream_t stream) {
   ChainArgs a = {};
+  a.npl = agcn_npl();
   // optional fused 1x1 term (backward-data only): out += W2^T . in2 with w2 (K2, M) row-major, e.g. the theta/phi
   // branch  dx += Wab^T dtp  (reference agcn.py:99-100 differentiated)
   a.in2 = (in2 && w2 && K2 > 0) ? in2 : nullptr;
@@ -769,6 +776,7 @@ size_t agcn_gcn_dadj_chain_workspace(int C, int Cout) {
 int agcn_gcn_dadj_chain(const float* dy, const float* wcat, const float* x, float* dadj_part, void* ws, size_t ws_bytes,
                         int N, int C, int Cout, int T, int V, hipStream_t stream) {
   DadjArgs a = {};
+  a.npl = agcn_npl();
   a.dy = dy; a.x = x; a.dpart = dadj_part; a.N = N; a.C = C; a.Cout = Cout; a.T = T; a.V = V;
   if (C % 128 == 0) return dadj_chain_launch<4, DADJ_NW>(a, wcat, ws, ws_bytes, stream);
   return dadj_chain_launch<2, DADJ_NW64>(a, wcat, ws, ws_bytes, stream);

@@ -24,13 +24,17 @@ __device__ __forceinline__ void sb_split_pair(float a, float b, unsigned& ph, un
   pl = sb_pack_bf16(ra - sb_lo_as_f32(pm), rb - sb_hi_as_f32(pm));
 }
 
-// the six products of one 32x32x16 step, smallest first (a*/b*: hi, mid, lo fragments)
-__device__ __forceinline__ f32x16 sb_mfma6(bf16x8 a0, bf16x8 a1, bf16x8 a2, bf16x8 b0, bf16x8 b1, bf16x8 b2, f32x16 c) {
-  c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, b0, c, 0, 0, 0);
-  c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b2, c, 0, 0, 0);
-  c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b1, c, 0, 0, 0);
-  c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b0, c, 0, 0, 0);
-  c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b1, c, 0, 0, 0);
+// the products of one 32x32x16 step, smallest first (a*/b*: hi, mid, lo fragments).  npl (wave-uniform): 3 = the six
+// products of the fp32-equivalent split, 1 = the hi*hi product only (plain bf16 arithmetic, BASELINE configs[3]).
+__device__ __forceinline__ f32x16 sb_mfma6(bf16x8 a0, bf16x8 a1, bf16x8 a2, bf16x8 b0, bf16x8 b1, bf16x8 b2, f32x16 c,
+                                           int npl = 3) {
+  if (npl == 3) {
+    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, b0, c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b2, c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b1, c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b0, c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b1, c, 0, 0, 0);
+  }
   c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b0, c, 0, 0, 0);
   return c;
 }

@@ -87,6 +87,7 @@ struct W9Args {
   float* part;        // [nsplit][9][M][C]
   int N, M, C, V, T, Tp;
   int nchunk, units, units_per_split, ncb;
+  int npl;            // 3: six split products (bf16x6) ; 1: hi*hi only (bf16)
 };
 
 // elements s .. s+7 of a 16-element window held as 8 packed bf16 pairs
@@ -105,8 +106,8 @@ __device__ __forceinline__ bf16x8 window_frag(const unsigned (&p)[8]) {
 
 template <int S>
 __device__ __forceinline__ f32x16 tap_mfma(bf16x8 a0, bf16x8 a1, bf16x8 a2, const unsigned (&p0)[8],
-                                           const unsigned (&p1)[8], const unsigned (&p2)[8], f32x16 c) {
-  return sb_mfma6(a0, a1, a2, window_frag<S>(p0), window_frag<S>(p1), window_frag<S>(p2), c);
+                                           const unsigned (&p1)[8], const unsigned (&p2)[8], f32x16 c, int npl) {
+  return sb_mfma6(a0, a1, a2, window_frag<S>(p0), window_frag<S>(p1), window_frag<S>(p2), c, npl);
 }
 
 // RT x CT = 4 waves: (4, 1) = 128 rows x 32 channels, (2, 2) = 64 rows x 64 channels.  Two workgroups share a CU
@@ -233,25 +234,25 @@ __global__ void __launch_bounds__(256, 2) wgrad9_bf16_kernel(const W9Args a) {
       const bf16x8 a0 = __builtin_bit_cast(bf16x8, ah), a1 = __builtin_bit_cast(bf16x8, am),
                    a2 = __builtin_bit_cast(bf16x8, al);
       if (STRIDE == 1) {                           // tap k = window shift k
-        acc[0] = tap_mfma<0>(a0, a1, a2, p0, p1, p2, acc[0]);
-        acc[1] = tap_mfma<1>(a0, a1, a2, p0, p1, p2, acc[1]);
-        acc[2] = tap_mfma<2>(a0, a1, a2, p0, p1, p2, acc[2]);
-        acc[3] = tap_mfma<3>(a0, a1, a2, p0, p1, p2, acc[3]);
-        acc[4] = tap_mfma<4>(a0, a1, a2, p0, p1, p2, acc[4]);
-        acc[5] = tap_mfma<5>(a0, a1, a2, p0, p1, p2, acc[5]);
-        acc[6] = tap_mfma<6>(a0, a1, a2, p0, p1, p2, acc[6]);
-        acc[7] = tap_mfma<7>(a0, a1, a2, p0, p1, p2, acc[7]);
-        acc[8] = tap_mfma<8>(a0, a1, a2, p0, p1, p2, acc[8]);
+        acc[0] = tap_mfma<0>(a0, a1, a2, p0, p1, p2, acc[0], a.npl);
+        acc[1] = tap_mfma<1>(a0, a1, a2, p0, p1, p2, acc[1], a.npl);
+        acc[2] = tap_mfma<2>(a0, a1, a2, p0, p1, p2, acc[2], a.npl);
+        acc[3] = tap_mfma<3>(a0, a1, a2, p0, p1, p2, acc[3], a.npl);
+        acc[4] = tap_mfma<4>(a0, a1, a2, p0, p1, p2, acc[4], a.npl);
+        acc[5] = tap_mfma<5>(a0, a1, a2, p0, p1, p2, acc[5], a.npl);
+        acc[6] = tap_mfma<6>(a0, a1, a2, p0, p1, p2, acc[6], a.npl);
+        acc[7] = tap_mfma<7>(a0, a1, a2, p0, p1, p2, acc[7], a.npl);
+        acc[8] = tap_mfma<8>(a0, a1, a2, p0, p1, p2, acc[8], a.npl);
       } else {                                     // even taps: xE shifted by 4 + (k-4)/2 ; odd taps: xO by 4 + (k-5)/2
-        acc[0] = tap_mfma<2>(a0, a1, a2, p0, p1, p2, acc[0]);
-        acc[1] = tap_mfma<2>(a0, a1, a2, o0, o1, o2, acc[1]);
-        acc[2] = tap_mfma<3>(a0, a1, a2, p0, p1, p2, acc[2]);
-        acc[3] = tap_mfma<3>(a0, a1, a2, o0, o1, o2, acc[3]);
-        acc[4] = tap_mfma<4>(a0, a1, a2, p0, p1, p2, acc[4]);
-        acc[5] = tap_mfma<4>(a0, a1, a2, o0, o1, o2, acc[5]);
-        acc[6] = tap_mfma<5>(a0, a1, a2, p0, p1, p2, acc[6]);
-        acc[7] = tap_mfma<5>(a0, a1, a2, o0, o1, o2, acc[7]);
-        acc[8] = tap_mfma<6>(a0, a1, a2, p0, p1, p2, acc[8]);
+        acc[0] = tap_mfma<2>(a0, a1, a2, p0, p1, p2, acc[0], a.npl);
+        acc[1] = tap_mfma<2>(a0, a1, a2, o0, o1, o2, acc[1], a.npl);
+        acc[2] = tap_mfma<3>(a0, a1, a2, p0, p1, p2, acc[2], a.npl);
+        acc[3] = tap_mfma<3>(a0, a1, a2, o0, o1, o2, acc[3], a.npl);
+        acc[4] = tap_mfma<4>(a0, a1, a2, p0, p1, p2, acc[4], a.npl);
+        acc[5] = tap_mfma<4>(a0, a1, a2, o0, o1, o2, acc[5], a.npl);
+        acc[6] = tap_mfma<5>(a0, a1, a2, p0, p1, p2, acc[6], a.npl);
+        acc[7] = tap_mfma<5>(a0, a1, a2, o0, o1, o2, acc[7], a.npl);
+        acc[8] = tap_mfma<6>(a0, a1, a2, p0, p1, p2, acc[8], a.npl);
       }
     }
   }
@@ -318,7 +319,7 @@ int w9_launch(const W9Args& a, const W9Geom& g, hipStream_t s) {
 // stride-1 9-tap problems whose rows and channels tile by 64 (every unit_tcn of the AGCN/AAGCN stacks except the two
 // stride-2 ones)
 bool agcn_wgrad9_bf16_supported(int M, int C, int V, int stride) {
-  if (M % 64 != 0 || C % 64 != 0 || V < 1 || V > 32 || agcn_gemm_precision() != 3) return false;
+  if (M % 64 != 0 || C % 64 != 0 || V < 1 || V > 32 || !agcn_chained()) return false;
   return stride == 1 || (stride == 2 && M % 128 == 0);      // (stride 2 only with the 128-row tile: LDS budget)
 }
 
@@ -346,6 +347,7 @@ int agcn_wgrad9_bf16(const float* dy, const float* x, void* ws, size_t ws_bytes,
   a.dyT = dyT; a.xT = xT; a.part = (float*)ws;
   a.N = N; a.M = M; a.C = C; a.V = V; a.T = To; a.Tp = g.Tp;
   a.nchunk = g.nchunk; a.units = g.units; a.units_per_split = g.units_per_split; a.ncb = g.ncb;
+  a.npl = agcn_npl();
   *nslabs = g.nsplit;
   if (stride == 2) return w9_launch<4, 1, 2>(a, g, s);
   return g.rt == 4 ? w9_launch<4, 1, 1>(a, g, s) : w9_launch<2, 2, 1>(a, g, s);

@@ -28,7 +28,7 @@ struct WcArgs {
   int N, M, C, V, T_src, T_out, stride;
   int ntiles, pairs_per_split, ncg;   // frame tiles per sample, (sample, tile) pairs per blockIdx.y, channel groups
   int XP;                              // pitch (floats) of a staged x row (odd)
-  long wsize;
+  long wsize;  int npl;             // 3: six split products (bf16x6) ; 1: hi*hi only (bf16)
 };
 
 __device__ __forceinline__ unsigned wc_pack_bf16(float a, float b) {
@@ -220,11 +220,13 @@ __global__ void __launch_bounds__(NW * 64, 2) wgrad_chain_kernel(const WcArgs a)
           const bf16x8 a0 = *reinterpret_cast<const bf16x8*>(ab + ((0 * FT * 4) * BM + tm * 32) * 16);
           const bf16x8 a1 = *reinterpret_cast<const bf16x8*>(ab + ((1 * FT * 4) * BM + tm * 32) * 16);
           const bf16x8 a2 = *reinterpret_cast<const bf16x8*>(ab + ((2 * FT * 4) * BM + tm * 32) * 16);
-          acc[tm] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, b0, acc[tm], 0, 0, 0);
-          acc[tm] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b2, acc[tm], 0, 0, 0);
-          acc[tm] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b1, acc[tm], 0, 0, 0);
-          acc[tm] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b0, acc[tm], 0, 0, 0);
-          acc[tm] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b1, acc[tm], 0, 0, 0);
+          if (a.npl == 3) {
+            acc[tm] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, b0, acc[tm], 0, 0, 0);
+            acc[tm] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b2, acc[tm], 0, 0, 0);
+            acc[tm] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b1, acc[tm], 0, 0, 0);
+            acc[tm] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b0, acc[tm], 0, 0, 0);
+            acc[tm] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b1, acc[tm], 0, 0, 0);
+          }
           acc[tm] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b0, acc[tm], 0, 0, 0);
         }
       }
@@ -354,6 +356,7 @@ size_t agcn_wgrad_chain_workspace(int agg, int N, int M, int C, int V, int T_out
 int agcn_wgrad_chain(int agg, const float* dy, const float* x, const float* adj, void* ws, size_t ws_bytes, int* nslabs,
                      int N, int M, int C, int V, int T_src, int T_out, int stride, hipStream_t s) {
   WcArgs a = {};
+  a.npl = agcn_npl();
   a.dy = dy; a.in = x; a.adj = adj; a.N = N; a.M = M; a.C = C; a.V = V; a.T_src = T_src; a.T_out = T_out;
   a.stride = stride; a.wsize = (long)(agg ? 3 : 1) * M * C;
   const bool tm4 = M > 64 && C % 64 == 0;

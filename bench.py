@@ -31,6 +31,8 @@ WORKLOADS = {
     # name: (model module, num_class, num_point, graph, default per-GPU batch, description)
     'ntu_agcn': ('agcn', 60, 25, 'graph.ntu_rgb_d.Graph', 64, 'AGCN joint-stream NTU-xview shape'),
     'ntu_aagcn': ('aagcn', 60, 25, 'graph.ntu_rgb_d.Graph', 64, 'AAGCN (attention) NTU-xsub shape, fp32'),
+    # BASELINE configs[3]: plain bf16 MFMA operands (one product per fp32 product), fp32 accumulate / storage / master weights
+    'ntu_aagcn_bf16': ('aagcn', 60, 25, 'graph.ntu_rgb_d.Graph', 64, 'AAGCN (attention) NTU-xsub shape, bf16 MFMA'),
     'kinetics_agcn': ('agcn', 400, 18, 'graph.kinetics.Graph', 128, 'AGCN Kinetics-Skeleton shape (N,3,300,18,2)'),
 }
 
@@ -274,6 +276,8 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-roofline', action='store_true')
     args = ap.parse_args()
+    if args.workload.endswith('_bf16'):
+        os.environ['AGCN_GEMM'] = 'bf16'          # fixed per process, read by the library on first use
 
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
@@ -333,7 +337,8 @@ def main():
     if rank == 0:
         from agcn_amd import lib as _lib
         gemm_mode = _lib.load().agcn_gemm_mode().decode()
-        dtype_label = "f32" if gemm_mode in ('bf16x6', 'f32') else "bf16x3 (reduced precision: INVALID as a headline)"
+        dtype_label = ("f32" if gemm_mode in ('bf16x6', 'f32') else
+                       "bf16" if gemm_mode == 'bf16' else "bf16x3 (reduced precision: INVALID as a headline)")
         clips = args.batch * world * args.steps
         out = {
             "metric": "skeleton-clips/sec fwd+bwd, NTU (N,3,300,25,2)" if wl[2] == 25 else
@@ -350,11 +355,15 @@ def main():
                                                        "fp32-equivalent, dropped terms < 2^-24 |ab|)"
                                                        if gemm_mode == 'bf16x6' else
                                                        " (exact-f32 MFMA)" if gemm_mode == 'f32' else
+                                                       " (plain bf16 MFMA operands, one product per fp32 product, fp32 "
+                                                       "accumulate, fp32 storage and master weights: BASELINE "
+                                                       "configs[3]; tolerance 2e-2 vs the fp32 oracle)"
+                                                       if gemm_mode == 'bf16' else
                                                        " (3 bf16 products: NOT fp32-equivalent, fails the 1e-4 parity "
                                                        "bar; diagnostic mode only)")},
             "final_loss": round(final_loss, 5),
         }
-        if world == 1 and not args.no_roofline and args.workload == 'ntu_agcn':
+        if world == 1 and not args.no_roofline and args.workload in ('ntu_agcn', 'ntu_aagcn', 'ntu_aagcn_bf16'):
             out["roofline"] = dominant_kernel_roofline(device)
             out["unit_gcn_fwd"] = unit_gcn_forward_roofline(device)
             print("[bench] roofline done", file=sys.stderr, flush=True)

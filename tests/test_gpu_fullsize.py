@@ -109,3 +109,19 @@ def test_exact_f32_mfma_mode_passes_the_kernel_suite():
     tail = (r.stdout + r.stderr)[-1500:]
     assert r.returncode == 0, tail
     print(tail.strip().splitlines()[-1])
+
+
+def test_plain_bf16_mode_holds_its_tolerance():
+    """BASELINE configs[3] (AAGCN, bf16): AGCN_GEMM=bf16 runs every channel contraction with plain bf16 MFMA operands
+    (one product, fp32 accumulate).  The mode is per process, so tests/bf16_check.py runs in its own: AAGCN unit and
+    model fixtures (generated from the fp32 reference) at 2e-2 on outputs, 5e-2 on parameter gradients."""
+    _gpu()
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, 'tests', 'bf16_check.py')], env=dict(os.environ, AGCN_GEMM='bf16'),
+                       cwd=root, capture_output=True, text=True, timeout=900)
+    out = (r.stdout + r.stderr)
+    print('\n'.join(ln for ln in out.splitlines() if ln.startswith(('bf16', '  FAIL'))))
+    assert r.returncode == 0, out[-2500:]
