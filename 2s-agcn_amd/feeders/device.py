@@ -52,33 +52,57 @@ class DeviceLoader:
         return out, ev
 
     def __iter__(self):
-        ring, it, slot = [], iter(self.loader), 0
-        nslots = self.depth + 1
+        """A feeder thread pulls host batches, stages them in pinned buffers and enqueues the H2D copies on the side
+        stream, up to ``depth`` batches ahead; the consumer only pops finished (tensors, event) pairs, so the host work
+        of batch k+1 (worker hand-over, 11.5 MB memcpy into pinned memory) overlaps the training step of batch k."""
+        import queue
+        import threading
+        q = queue.Queue(maxsize=self.depth)
+        nslots = self.depth + 2
         busy = [None] * nslots          # event after which a slot's pinned buffers may be overwritten
+        stop = threading.Event()
 
-        def push():
-            nonlocal slot
+        def feed():
             try:
-                batch = next(it)
-            except StopIteration:
-                return False
-            if busy[slot] is not None:
-                busy[slot].synchronize()           # the copy that last used these pinned buffers has finished
-            ring.append((slot,) + self._stage(slot, batch))
-            slot = (slot + 1) % nslots
-            return True
-        for _ in range(self.depth):
-            if not push():
-                break
-        while ring:
-            s, tensors, ev = ring.pop(0)
-            if ev is not None:
-                torch.cuda.current_stream(self.device).wait_event(ev)
-                for t in tensors:
-                    t.record_stream(torch.cuda.current_stream(self.device))
-                busy[s] = ev
-            push()
-            yield tuple(tensors)
+                if self.device.type == 'cuda':
+                    torch.cuda.set_device(self.device)
+                slot = 0
+                for batch in self.loader:
+                    if stop.is_set():
+                        return
+                    if busy[slot] is not None:
+                        busy[slot].synchronize()       # the copy that last used these pinned buffers has finished
+                    tensors, ev = self._stage(slot, batch)
+                    busy[slot] = ev
+                    q.put((tensors, ev))
+                    slot = (slot + 1) % nslots
+                q.put(None)
+            except BaseException as e:                 # surface loader errors in the consumer
+                q.put(e)
+        th = threading.Thread(target=feed, daemon=True)
+        th.start()
+        try:
+            while True:
+                item = q.get()
+                if item is None:
+                    break
+                if isinstance(item, BaseException):
+                    raise item
+                tensors, ev = item
+                if ev is not None:
+                    cur = torch.cuda.current_stream(self.device)
+                    cur.wait_event(ev)
+                    for t in tensors:
+                        t.record_stream(cur)
+                yield tuple(tensors)
+        finally:
+            stop.set()
+            while th.is_alive():                       # unblock a feeder waiting on a full queue
+                try:
+                    q.get_nowait()
+                except queue.Empty:
+                    pass
+                th.join(timeout=0.05)
 
 
 class DeviceAugment:

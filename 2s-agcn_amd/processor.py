@@ -137,6 +137,19 @@ class NpyFeeder(torch.utils.data.Dataset):
         return np.asarray(self.data[i], dtype=np.float32), self.label[i], i
 
 
+class _IndexSampler(torch.utils.data.Sampler):
+    """Yields the index list it currently holds (set per epoch by ``Processor._loader``)."""
+
+    def __init__(self):
+        self.indices = []
+
+    def __iter__(self):
+        return iter(list(self.indices))
+
+    def __len__(self):
+        return len(self.indices)
+
+
 class Processor:
     def __init__(self, arg):
         self.arg = arg
@@ -216,7 +229,7 @@ class Processor:
         transforms get them applied batch-wise on the device (feeders.DeviceAugment)."""
         from .feeders import DeviceAugment
         Feeder = import_class(self.arg.feeder)
-        self.datasets, self.augment = {}, {}
+        self.datasets, self.augment, self._loaders = {}, {}, {}
 
         def build(kwargs, train):
             kw = dict(kwargs)
@@ -246,8 +259,16 @@ class Processor:
         per = (n + self.world - 1) // self.world
         order = order + order[:per * self.world - n]
         idx = order[self.rank::self.world]
-        dl = torch.utils.data.DataLoader(torch.utils.data.Subset(ds, idx), batch_size=bs, shuffle=False,
-                                         drop_last=drop, num_workers=self.arg.num_worker)
+        # ONE DataLoader per split for the whole run (persistent workers: forking and warming them per epoch would
+        # cost seconds); the epoch's index list is swapped into its sampler
+        if name not in self._loaders:
+            sampler = _IndexSampler()
+            nw = int(self.arg.num_worker)
+            dl = torch.utils.data.DataLoader(ds, batch_size=bs, sampler=sampler, drop_last=drop, num_workers=nw,
+                                             persistent_workers=nw > 0, prefetch_factor=4 if nw > 0 else None)
+            self._loaders[name] = (dl, sampler)
+        dl, sampler = self._loaders[name]
+        sampler.indices = idx
         return DeviceLoader(dl, self.device, depth=self.arg.prefetch_depth), idx
 
     # ---- one epoch ------------------------------------------------------------------------------------------------
@@ -256,7 +277,10 @@ class Processor:
         freeze_pa = self.arg.only_train_part and epoch <= self.arg.only_train_epoch
         self.print_log(f'Training epoch: {epoch + 1}, lr {self.engine.lr:.6f}')
         # the reference's three buckets (processor.py:608, 670, 709, 752, 759-775): waiting for data / the step /
-        # statistics + logging.  The device is synchronised at the bucket borders so the split is real time.
+        # statistics + logging, as host wall time like the reference.  Nothing synchronises the device inside the loop
+        # (the step is asynchronous; the host runs ahead of the GPU), so `dataloader` is the time the training thread
+        # actually WAITED for its next batch; the device is drained once at the end of the epoch and that wait is
+        # booked on `model`.
         timer = dict(dataloader=0.0, model=0.0, statistics=0.0)
         losses = []
         loader, _ = self._loader('train', epoch)
@@ -269,17 +293,15 @@ class Processor:
             dt, mark = now - mark, now
             return dt
         for step, (data, label, _) in enumerate(loader):
+            timer['dataloader'] += split()
             data = data.float()
             if aug is not None:
                 data = aug(data)
-            torch.cuda.current_stream().synchronize()
-            timer['dataloader'] += split()
             if freeze_pa:
                 loss = self._train_step_frozen_pa(data, label)
             else:
                 loss = self.engine.train_step(data, label)
             self.global_step += 1
-            torch.cuda.current_stream().synchronize()
             timer['model'] += split()
             if step % self.arg.log_interval == 0:
                 losses.append(float(loss.detach()))
@@ -288,6 +310,8 @@ class Processor:
             timer['statistics'] += split()
             if self.arg.max_steps_per_epoch and step + 1 >= self.arg.max_steps_per_epoch:
                 break
+        torch.cuda.current_stream().synchronize()
+        timer['model'] += split()
         tot = max(sum(timer.values()), 1e-9)
         self.last_timer = dict(timer)
         self.print_log(f'\tMean training loss: {np.mean(losses) if losses else float("nan"):.4f}.')

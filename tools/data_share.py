@@ -12,8 +12,8 @@ import agcn_amd  # noqa: F401
 from agcn_amd.processor import Processor, load_args
 
 ap = argparse.ArgumentParser()
-ap.add_argument('--samples', type=int, default=512)
-ap.add_argument('--workers', type=int, default=4)
+ap.add_argument('--samples', type=int, default=1536)
+ap.add_argument('--workers', type=int, default=8)
 ap.add_argument('--host-augment', action='store_true', help='per-sample numpy transforms on the host (the reference way)')
 a = ap.parse_args()
 tmp = tempfile.mkdtemp(prefix='agcn_data_')
