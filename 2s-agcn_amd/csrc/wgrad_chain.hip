@@ -28,7 +28,9 @@ struct WcArgs {
   int N, M, C, V, T_src, T_out, stride;
   int ntiles, pairs_per_split, ncg;   // frame tiles per sample, (sample, tile) pairs per blockIdx.y, channel groups
   int XP;                              // pitch (floats) of a staged x row (odd)
-  long wsize;  int npl;             // 3: six split products (bf16x6) ; 1: hi*hi only (bf16)
+  long wsize;
+  int npl;             // 3: six split products (bf16x6) ; 1: hi*hi only (bf16)
+  int pad;             // 1: [o] blocks of the dy image padded by one slot (AGCN_WC_PAD=0 for the A/B measurement)
 };
 
 __device__ __forceinline__ unsigned wc_pack_bf16(float a, float b) {
@@ -62,8 +64,13 @@ __global__ void __launch_bounds__(NW * 64, 2) wgrad_chain_kernel(const WcArgs a)
   constexpr int XR = CG / NW;                   // x rows per wave
   constexpr int XB = (FT * 32 + 63) / 64;       // 64-float column blocks of an x row
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  unsigned char* dyi = smem;                                        // [plane][f][ks][h][o][8] bf16
-  constexpr int DY_BYTES = 3 * FT * 4 * BM * 16;
+  // [plane][f][ks][h][o (BMP slots)][8] bf16.  Each [o] block is padded by one 16-byte slot: the staging threads walk
+  // (f, ks, h) fastest, i.e. from block to block, and with a power-of-two block every ds_write_b128 of a wave hit the
+  // same banks (measured: 60 % of the kernel's LDS cycles were bank conflicts); BM+1 slots put the 8 lanes of a
+  // write group on 8 different 16-byte columns.  Fragment reads walk o (consecutive slots) and are unaffected.
+  const int BMP = BM + a.pad;
+  unsigned char* dyi = smem;
+  const int DY_BYTES = 3 * FT * 4 * BMP * 16;
   float* xs = reinterpret_cast<float*>(smem + DY_BYTES);            // [CG][XP]
   float* adjp = xs + CG * a.XP;                                     // [32][32] (AGG)
 
@@ -135,10 +142,10 @@ __global__ void __launch_bounds__(NW * 64, 2) wgrad_chain_kernel(const WcArgs a)
         wc_split_pair(v0, v1, q0, q1, q2);
         ph[e2] = q0; pm[e2] = q1; pl[e2] = q2;
       }
-      const int slot = ((f * 2 + ks) * 2 + hh) * BM + o;
-      *reinterpret_cast<u32x4*>(dyi + ((0 * FT * 4) * BM + slot) * 16) = ph;
-      *reinterpret_cast<u32x4*>(dyi + ((1 * FT * 4) * BM + slot) * 16) = pm;
-      *reinterpret_cast<u32x4*>(dyi + ((2 * FT * 4) * BM + slot) * 16) = pl;
+      const int slot = ((f * 2 + ks) * 2 + hh) * BMP + o;
+      *reinterpret_cast<u32x4*>(dyi + ((0 * FT * 4) * BMP + slot) * 16) = ph;
+      *reinterpret_cast<u32x4*>(dyi + ((1 * FT * 4) * BMP + slot) * 16) = pm;
+      *reinterpret_cast<u32x4*>(dyi + ((2 * FT * 4) * BMP + slot) * 16) = pl;
     }
 #pragma unroll
     for (int j = 0; j < XR; ++j) {
@@ -214,12 +221,12 @@ __global__ void __launch_bounds__(NW * 64, 2) wgrad_chain_kernel(const WcArgs a)
         }
         const bf16x8 b0 = __builtin_bit_cast(bf16x8, gh), b1 = __builtin_bit_cast(bf16x8, gm),
                      b2 = __builtin_bit_cast(bf16x8, gl);
-        const unsigned char* ab = dyi + ((((f * 2 + ks) * 2 + h) * BM) + lr) * 16;
+        const unsigned char* ab = dyi + ((((f * 2 + ks) * 2 + h) * BMP) + lr) * 16;
 #pragma unroll
         for (int tm = 0; tm < TM; ++tm) {
-          const bf16x8 a0 = *reinterpret_cast<const bf16x8*>(ab + ((0 * FT * 4) * BM + tm * 32) * 16);
-          const bf16x8 a1 = *reinterpret_cast<const bf16x8*>(ab + ((1 * FT * 4) * BM + tm * 32) * 16);
-          const bf16x8 a2 = *reinterpret_cast<const bf16x8*>(ab + ((2 * FT * 4) * BM + tm * 32) * 16);
+          const bf16x8 a0 = *reinterpret_cast<const bf16x8*>(ab + ((0 * FT * 4) * BMP + tm * 32) * 16);
+          const bf16x8 a1 = *reinterpret_cast<const bf16x8*>(ab + ((1 * FT * 4) * BMP + tm * 32) * 16);
+          const bf16x8 a2 = *reinterpret_cast<const bf16x8*>(ab + ((2 * FT * 4) * BMP + tm * 32) * 16);
           if (a.npl == 3) {
             acc[tm] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, b0, acc[tm], 0, 0, 0);
             acc[tm] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b2, acc[tm], 0, 0, 0);
@@ -258,7 +265,7 @@ WcGeom wc_geom(int N, int M, int C, int V, int T_out) {
   g.ncg = (C + CG - 1) / CG;
   g.nmb = (M + BM - 1) / BM;
   g.XP = (FT * V) | 1;
-  g.smem_bytes = (size_t)3 * FT * 4 * BM * 16 + (size_t)CG * g.XP * 4 + (AGG ? 32 * 32 * 4 : 0);
+  g.smem_bytes = (size_t)3 * FT * 4 * (BM + 1) * 16 + (size_t)CG * g.XP * 4 + (AGG ? 32 * 32 * 4 : 0);   // sized for pad = 1
   g.grid_x = g.nmb * g.ncg * (AGG ? 3 : 1);
   const int pairs = N * g.ntiles;
   int want = (256 * 8 / NW) / g.grid_x;  // one 8-wave (or two 4-wave) workgroups per CU
@@ -357,6 +364,7 @@ int agcn_wgrad_chain(int agg, const float* dy, const float* x, const float* adj,
                      int N, int M, int C, int V, int T_src, int T_out, int stride, hipStream_t s) {
   WcArgs a = {};
   a.npl = agcn_npl();
+  { const char* e = getenv("AGCN_WC_PAD"); a.pad = (e && atoi(e) == 0) ? 0 : 1; }
   a.dy = dy; a.in = x; a.adj = adj; a.N = N; a.M = M; a.C = C; a.V = V; a.T_src = T_src; a.T_out = T_out;
   a.stride = stride; a.wsize = (long)(agg ? 3 : 1) * M * C;
   const bool tm4 = M > 64 && C % 64 == 0;

@@ -129,9 +129,10 @@ def dominant_kernel_roofline(device, reps=10):
     if mode == 'f32':
         peak, note = PEAK_FP32_MFMA_TFLOPS, 'exact-f32 MFMA'
     else:
-        products = 3 if mode == 'bf16x3' else 6
+        products = {'bf16x6': 6, 'bf16x3': 3, 'bf16': 1}[mode]
         peak = round(PEAK_BF16_MFMA_TFLOPS / products, 1)
-        note = f'{products} bf16 MFMA products per fp32 product, fp32 accumulate: peak = {PEAK_BF16_MFMA_TFLOPS:.0f}/{products}'
+        note = (f'{products} bf16 MFMA product(s) per fp32 product, fp32 accumulate: peak = '
+                f'{PEAK_BF16_MFMA_TFLOPS:.0f}/{products}')
     traffic, src = pmc_traffic(kernel)
     return {"bound": "mfma", "kernel": kernel, "what": "unit_tcn 9x1 conv forward, l9-l10 shape (N'=128, C=256, T=75, V=25)",
             "arithmetic": note, "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
@@ -160,7 +161,8 @@ def unit_gcn_forward_roofline(device, reps=5, Np=128, V=25):
     from agcn_amd.graph.ntu_rgb_d import Graph
     A = Graph().A
     mode = ops._L().agcn_gemm_mode().decode()
-    split_peak = PEAK_FP32_MFMA_TFLOPS if mode == 'f32' else PEAK_BF16_MFMA_TFLOPS / (3 if mode == 'bf16x3' else 6)
+    split_peak = (PEAK_FP32_MFMA_TFLOPS if mode == 'f32' else
+                  PEAK_BF16_MFMA_TFLOPS / {'bf16x6': 6, 'bf16x3': 3, 'bf16': 1}[mode])
     rows = []
     for name, C, Cout, T in GCN_LAYER_SHAPES:
         torch.manual_seed(0)
