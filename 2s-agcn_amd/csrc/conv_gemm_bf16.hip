@@ -42,6 +42,7 @@ struct BfArgs {
   int nchunks, nmb;
   int off_b;                   // byte offset of the B image in LDS
   int off_bias;                // byte offset of the bias row in LDS
+  int dbg;                     // profiling switches (AGCN_CB_DBG): 1 = no MFMA loop, 2 = stage chunk 0 only, 4 = no epilogue
 };
 
 struct BfPackArgs {
@@ -100,7 +101,7 @@ __global__ void __launch_bounds__(256) pack_weights_bf16_kernel(const BfPackArgs
 // TN = 32-position tiles per wave (2: 64-row blocks cover 512 positions, so every weight fragment feeds two MFMAs and
 // the 8-frame halo of the window is amortised over 20 frames instead of 10)
 template <int TAPS, int NPL, int WQ, int TM, int TN = 1>
-__global__ void __launch_bounds__(NT, (TAPS == 1 && TM == 2) ? 4 : 2) conv_gemm_bf16_kernel(const BfArgs a) {
+__global__ void __launch_bounds__(NT, (TAPS == 1 && TM == 2 && TN == 1) ? 4 : 2) conv_gemm_bf16_kernel(const BfArgs a) {
   constexpr int BM = TM * 32;
   constexpr int A_PLANE = TAPS * 2 * BM * 16;          // bytes per plane of the A image
   constexpr int A4 = NPL * A_PLANE / 16;               // 16-byte units of the A image that are used
@@ -202,41 +203,69 @@ __global__ void __launch_bounds__(NT, (TAPS == 1 && TM == 2) ? 4 : 2) conv_gemm_
   if (nchunks > 0) issue_loads(0);
   for (int ch = 0; ch < nchunks; ++ch) {
     __syncthreads();
-    commit_lds(ch);
-    if (ch + 1 < nchunks) issue_loads(ch + 1);
+    if (!(a.dbg & 2) || ch == 0) {
+      commit_lds(ch);
+      if (ch + 1 < nchunks) issue_loads(ch + 1);
+    }
     __syncthreads();
-#pragma unroll 1
-    for (int tap = 0; tap < TAPS; ++tap) {
-      bf16x8 af[NPL][TM], bf[NPL][TN];
+    if (a.dbg & 1) continue;
+    // the fragments of the next (tap, row tile) step are read from LDS while this step's MFMAs run
+    bf16x8 afc[NPL], bfc[NPL][TN];
+    auto load_a = [&](bf16x8 (&af)[NPL], int tap, int tm) __attribute__((always_inline)) {
 #pragma unroll
-      for (int pl = 0; pl < NPL; ++pl) {
+      for (int pl = 0; pl < NPL; ++pl)
+        af[pl] = *reinterpret_cast<const bf16x8*>(Ab + pl * A_PLANE + (((tap * 2 + h) * BM) + tm * 32 + lr) * 16);
+    };
+    auto load_b = [&](bf16x8 (&bf)[NPL][TN], int tap) __attribute__((always_inline)) {
 #pragma unroll
-        for (int tm = 0; tm < TM; ++tm)
-          af[pl][tm] = *reinterpret_cast<const bf16x8*>(Ab + pl * A_PLANE + (((tap * 2 + h) * BM) + tm * 32 + lr) * 16);
+      for (int pl = 0; pl < NPL; ++pl)
 #pragma unroll
         for (int tn = 0; tn < TN; ++tn)
           bf[pl][tn] = *reinterpret_cast<const bf16x8*>(Bb + ((pl * 2 + h) * WLR + boff[tn] + tap * V) * 16);
-      }
+    };
+    load_b(bfc, 0);
+    load_a(afc, 0, 0);
+    __builtin_amdgcn_sched_group_barrier(0x100, NPL * (TN + 1), 0);
+#pragma unroll 1
+    for (int tap = 0; tap < TAPS; ++tap) {
+      bf16x8 bfn[NPL][TN];
+      const int tapn = min(tap + 1, TAPS - 1);       // the last tap re-reads its own fragments (unused)
 #pragma unroll
-      for (int tm = 0; tm < TM; ++tm)
+      for (int tm = 0; tm < TM; ++tm) {
+        bf16x8 afn[NPL];
+        load_a(afn, tm + 1 == TM ? tapn : tap, tm + 1 == TM ? 0 : tm + 1);
+        if (tm + 1 == TM) load_b(bfn, tapn);
 #pragma unroll
         for (int tn = 0; tn < TN; ++tn) {
           // smallest products first
           if (NPL == 3) {
-            acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[NPL - 1][tm], bf[0][tn], acc[tm][tn], 0, 0, 0);
-            acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0][tm], bf[NPL - 1][tn], acc[tm][tn], 0, 0, 0);
-            acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[NPL >= 2 ? 1 : 0][tm], bf[NPL >= 2 ? 1 : 0][tn], acc[tm][tn], 0, 0, 0);
+            acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afc[NPL - 1], bfc[0][tn], acc[tm][tn], 0, 0, 0);
+            acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afc[0], bfc[NPL - 1][tn], acc[tm][tn], 0, 0, 0);
+            acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afc[NPL >= 2 ? 1 : 0], bfc[NPL >= 2 ? 1 : 0][tn], acc[tm][tn], 0, 0, 0);
           }
           if (NPL >= 2) {
-            acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[NPL >= 2 ? 1 : 0][tm], bf[0][tn], acc[tm][tn], 0, 0, 0);
-            acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0][tm], bf[NPL >= 2 ? 1 : 0][tn], acc[tm][tn], 0, 0, 0);
+            acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afc[NPL >= 2 ? 1 : 0], bfc[0][tn], acc[tm][tn], 0, 0, 0);
+            acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afc[0], bfc[NPL >= 2 ? 1 : 0][tn], acc[tm][tn], 0, 0, 0);
           }
-          acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0][tm], bf[0][tn], acc[tm][tn], 0, 0, 0);
+          acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afc[0], bfc[0][tn], acc[tm][tn], 0, 0, 0);
         }
+        // pin the order "reads of the next step, then this step's MFMAs" (the scheduler otherwise sinks the reads to
+        // their uses and waits for each)
+        __builtin_amdgcn_sched_group_barrier(0x100, NPL, 0);
+        if (tm + 1 == TM) __builtin_amdgcn_sched_group_barrier(0x100, NPL * TN, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, TN * (NPL == 3 ? 6 : NPL == 2 ? 3 : 1), 0);
+#pragma unroll
+        for (int pl = 0; pl < NPL; ++pl) afc[pl] = afn[pl];
+      }
+#pragma unroll
+      for (int pl = 0; pl < NPL; ++pl)
+#pragma unroll
+        for (int tn = 0; tn < TN; ++tn) bfc[pl][tn] = bfn[pl][tn];
     }
   }
 
   // ---- epilogue (epilogue.h): tile -> LDS -> coalesced row stores, residual operands, (sum, sumsq) partials ----
+  if ((a.dbg & 4) && acc[0][0][0] != 12345.f) return;
   __syncthreads();                                     // every wave is done with the A/B images
   float* tile = reinterpret_cast<float*>(smem);        // [BM][TP]
   const int TP = NW * TN * 32 + 1;
@@ -312,6 +341,8 @@ int launch_bf(BfProblem& p, hipStream_t stream) {
   a.tt = g.tt; a.ntiles = g.ntiles; a.FW = g.FW; a.WLR = g.WLR; a.nchunks = g.nchunks; a.nmb = g.nmb;
   a.off_b = g.off_b; a.off_bias = g.off_bias;
   a.wp = (const unsigned short*)p.ws;
+  static const int dbg = getenv("AGCN_CB_DBG") ? atoi(getenv("AGCN_CB_DBG")) : 0;
+  a.dbg = dbg;
   if (g.nchunks > 0) {
     BfPackArgs pk;
     pk.w = p.w; pk.wp = (unsigned short*)p.ws; pk.M = a.M; pk.Kinner = a.Kinner; pk.nchunks = g.nchunks;

@@ -19,6 +19,7 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef f32x4 f32x4_u __attribute__((aligned(4)));     // rows of V floats are only 4-byte aligned
 
 struct WcArgs {
   const float* dy;     // (N, M, T_out, V)
@@ -30,6 +31,7 @@ struct WcArgs {
   int XP;                              // pitch (floats) of a staged x row (odd)
   long wsize;
   int npl;             // 3: six split products (bf16x6) ; 1: hi*hi only (bf16)
+  int dbg;             // profiling switches (AGCN_WC_DBG): 1 = no matrix work, 2 = stage the first pair only, 4 = no f32 chain
   int pad;             // 1: [o] blocks of the dy image padded by one slot (AGCN_WC_PAD=0 for the A/B measurement)
 };
 
@@ -98,9 +100,14 @@ __global__ void __launch_bounds__(NW * 64, 2) wgrad_chain_kernel(const WcArgs a)
     n = p / a.ntiles;
     t0 = (p - n * a.ntiles) * FT;
   };
+  // (tid is laundered inside the staging code: otherwise the per-thread item indices are hoisted out of the pair loop
+  // and held in registers across the matrix phase, which spills)
   auto issue = [&](int p) __attribute__((always_inline)) {
     int n, t0;
     pair_geom(p, n, t0);
+    int tid = threadIdx.x;
+    asm volatile("" : "+v"(tid));
+    const int lane = tid & 63;
 #pragma unroll
     for (int k = 0; k < DI; ++k) {
       const int item = tid + k * NT;                 // = o*(FT*4) + f*4 + (ks*2 + hh)
@@ -108,8 +115,20 @@ __global__ void __launch_bounds__(NW * 64, 2) wgrad_chain_kernel(const WcArgs a)
       const int f = r >> 2, ks = (r >> 1) & 1, hh = r & 1;
       const bool ok = (m0 + o) < a.M && (t0 + f) < a.T_out;
       const float* src = a.dy + ((long)n * a.M + (ok ? (m0 + o) : 0)) * Pout + (long)(ok ? (t0 + f) : 0) * V;
+      // the 8 joints of an item are two runs of 4 consecutive joints (wc_joint): one 16-byte load each when the run
+      // lies inside the frame, clamped scalar loads for a run that crosses the last joint
 #pragma unroll
-      for (int e = 0; e < 8; ++e) rdy[k][e] = src[min(wc_joint(ks, hh, e), V - 1)];
+      for (int run = 0; run < 2; ++run) {
+        const int v0 = 16 * ks + 4 * hh + 8 * run;
+        if (v0 + 3 < V) {
+          const f32x4 q = *reinterpret_cast<const f32x4_u*>(src + v0);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) rdy[k][4 * run + e] = q[e];
+        } else {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) rdy[k][4 * run + e] = src[min(v0 + e, V - 1)];
+        }
+      }
     }
 #pragma unroll
     for (int j = 0; j < XR; ++j) {
@@ -127,6 +146,9 @@ __global__ void __launch_bounds__(NW * 64, 2) wgrad_chain_kernel(const WcArgs a)
   auto commit = [&](int p) __attribute__((always_inline)) {
     int n, t0;
     pair_geom(p, n, t0);
+    int tid = threadIdx.x;
+    asm volatile("" : "+v"(tid));
+    const int lane = tid & 63;
 #pragma unroll
     for (int k = 0; k < DI; ++k) {
       const int item = tid + k * NT;
@@ -167,10 +189,11 @@ __global__ void __launch_bounds__(NW * 64, 2) wgrad_chain_kernel(const WcArgs a)
   if (p_begin < p_end) issue(p_begin);
   for (int p = p_begin; p < p_end; ++p) {
     __syncthreads();                          // every wave is done with the previous pair's LDS tiles
-    commit(p);
+    const bool stage = !(a.dbg & 2) || p == p_begin;
+    if (stage) commit(p);
     int n, t0;
     pair_geom(p, n, t0);
-    if (AGG && n != last_n) {
+    if (AGG && n != last_n && stage) {
       // zero-padded adjacency of this subset, adjp[u][v]
       const float* adjn = a.adj + ((long)n * 3 + isub) * V * V;
       for (int e = tid; e < 32 * 32; e += NT) {
@@ -181,16 +204,17 @@ __global__ void __launch_bounds__(NW * 64, 2) wgrad_chain_kernel(const WcArgs a)
       }
       last_n = n;
     }
-    if (p + 1 < p_end) issue(p + 1);          // in flight during this pair's matrix-core work
+    if (p + 1 < p_end && stage) issue(p + 1); // in flight during this pair's matrix-core work
     __syncthreads();
-#pragma unroll
+    if (a.dbg & 1) continue;
+#pragma unroll 1
     for (int k = 0; k < FPW; ++k) {
       const int f = fg + k * NFG;
       if (t0 + f >= a.T_out) continue;        // wave-uniform
       // ---- G^T[v][c] for (frame f, this wave's 32 channels) in D layout ----
       f32x16 d;
       const float* xr = xs + (cbw * 32 + lr) * XP + f * V;
-      if (AGG) {
+      if (AGG && !(a.dbg & 4)) {
 #pragma unroll
         for (int j = 0; j < 16; ++j) d[j] = 0.f;
         float ao[VS], xo[VS];
@@ -210,6 +234,7 @@ __global__ void __launch_bounds__(NW * 64, 2) wgrad_chain_kernel(const WcArgs a)
         }
       }
       // ---- split and contract with dy: acc[tm][o][c] += sum_v dy[o][v] * G^T[v][c] ----
+      bf16x8 gb[2][3];
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks) {
         u32x4 gh, gm, gl;
@@ -219,23 +244,40 @@ __global__ void __launch_bounds__(NW * 64, 2) wgrad_chain_kernel(const WcArgs a)
           wc_split_pair(d[8 * ks + 2 * e2], d[8 * ks + 2 * e2 + 1], q0, q1, q2);
           gh[e2] = q0; gm[e2] = q1; gl[e2] = q2;
         }
-        const bf16x8 b0 = __builtin_bit_cast(bf16x8, gh), b1 = __builtin_bit_cast(bf16x8, gm),
-                     b2 = __builtin_bit_cast(bf16x8, gl);
-        const unsigned char* ab = dyi + ((((f * 2 + ks) * 2 + h) * BMP) + lr) * 16;
+        gb[ks][0] = __builtin_bit_cast(bf16x8, gh);
+        gb[ks][1] = __builtin_bit_cast(bf16x8, gm);
+        gb[ks][2] = __builtin_bit_cast(bf16x8, gl);
+      }
+      // 2*TM steps of 6 MFMAs; the dy fragments of step s+1 are read while step s runs (order pinned below)
+      const unsigned char* ab = dyi + (((f * 4 + h) * BMP) + lr) * 16;
+      auto load_a = [&](bf16x8 (&af)[3], int step) __attribute__((always_inline)) {
+        const int ks = step / TM, tm = step - ks * TM;
 #pragma unroll
-        for (int tm = 0; tm < TM; ++tm) {
-          const bf16x8 a0 = *reinterpret_cast<const bf16x8*>(ab + ((0 * FT * 4) * BMP + tm * 32) * 16);
-          const bf16x8 a1 = *reinterpret_cast<const bf16x8*>(ab + ((1 * FT * 4) * BMP + tm * 32) * 16);
-          const bf16x8 a2 = *reinterpret_cast<const bf16x8*>(ab + ((2 * FT * 4) * BMP + tm * 32) * 16);
-          if (a.npl == 3) {
-            acc[tm] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, b0, acc[tm], 0, 0, 0);
-            acc[tm] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b2, acc[tm], 0, 0, 0);
-            acc[tm] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b1, acc[tm], 0, 0, 0);
-            acc[tm] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b0, acc[tm], 0, 0, 0);
-            acc[tm] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b1, acc[tm], 0, 0, 0);
-          }
-          acc[tm] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b0, acc[tm], 0, 0, 0);
+        for (int pl = 0; pl < 3; ++pl)
+          af[pl] = *reinterpret_cast<const bf16x8*>(ab + ((pl * FT * 4 + ks * 2) * BMP + tm * 32) * 16);
+      };
+      bf16x8 afc[3];
+      load_a(afc, 0);
+      __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);
+#pragma unroll
+      for (int step = 0; step < 2 * TM; ++step) {
+        const int ks = step / TM, tm = step - ks * TM;
+        bf16x8 afn[3];
+        if (step + 1 < 2 * TM) load_a(afn, step + 1);
+        if (a.npl == 3) {
+          acc[tm] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afc[2], gb[ks][0], acc[tm], 0, 0, 0);
+          acc[tm] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afc[0], gb[ks][2], acc[tm], 0, 0, 0);
+          acc[tm] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afc[1], gb[ks][1], acc[tm], 0, 0, 0);
+          acc[tm] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afc[1], gb[ks][0], acc[tm], 0, 0, 0);
+          acc[tm] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afc[0], gb[ks][1], acc[tm], 0, 0, 0);
         }
+        acc[tm] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afc[0], gb[ks][0], acc[tm], 0, 0, 0);
+        if (step + 1 < 2 * TM) {
+          __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);
+#pragma unroll
+          for (int pl = 0; pl < 3; ++pl) afc[pl] = afn[pl];
+        }
+        __builtin_amdgcn_sched_group_barrier(0x008, 6, 0);
       }
     }
   }
@@ -250,6 +292,287 @@ __global__ void __launch_bounds__(NW * 64, 2) wgrad_chain_kernel(const WcArgs a)
       const int c = c0 + cbw * 32 + lr;
       if (m < a.M && c < a.C) dst[(long)m * a.C + c] = acc[tm][j];
     }
+}
+
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Producer / consumer variant (C a multiple of 64).  Measured on the kernel above: staging (global loads, the bf16
+// split of dy, LDS writes: ~700 vector instructions per thread and stage) and the matrix phase were ADDITIVE, because
+// every wave did both between the same two barriers and the matrix pipe sat idle while all of them staged.  Here the
+// workgroup has NWC consumer waves, which only run the chain + contraction of stage p out of LDS buffer p&1, and NWP
+// producer waves, which meanwhile split stage p+1 into the other buffer (their global loads are issued one more stage
+// ahead, into registers).  One barrier per stage; the producers' vector work now overlaps the consumers' MFMAs on the
+// same SIMDs (3 waves per SIMD: 2 consumers + 1 producer).
+// AGG: the workgroup handles all three subsets (dy and x staged once, a third of the HBM/L2 traffic of one workgroup per
+// subset: measured, that variant ran at the memory system's pace); a consumer wave then holds 3*TM accumulator tiles.
+// NRB: 32*TM-row blocks per workgroup (consumer waves = NCB channel blocks x NFG frames x NRB row blocks)
+template <int AGG, int TM, int NCB, int VS, int NRB = 1, int NWC = 8, int NWP = 4>
+__global__ void __launch_bounds__((NWC + NWP) * 64, 3) wgrad_pc_kernel(const WcArgs a) {
+  constexpr int NTP = NWP * 64, BM = TM * 32 * NRB;
+  constexpr int NS = AGG ? 3 : 1;
+  constexpr int NFG = NWC / (NCB * NRB);        // frame groups = frames per stage (one frame per consumer wave)
+  constexpr int FT = NFG;
+  constexpr int CG = NCB * 32;
+  constexpr int DI = BM * FT * 4 / NTP;         // dy items (o, f, ks, h) per producer thread
+  static_assert(BM * FT * 4 % NTP == 0, "dy items must tile the producer threads");
+  constexpr int BMP = BM + 1;
+  constexpr int DY_BYTES = 3 * FT * 4 * BMP * 16;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int V = a.V, XP = a.XP;
+  const int FTV = FT * V;
+  const int BUF_BYTES = DY_BYTES + CG * XP * 4 + (AGG ? 3 * 32 * 32 * 4 : 0);
+  const long Pout = (long)a.T_out * V, Psrc = (long)a.T_src * V;
+
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int rest = (int)blockIdx.x;
+  const int cgp = rest % a.ncg, mb = rest / a.ncg;
+  const int m0 = mb * BM, c0 = cgp * CG;
+  const int total_pairs = a.N * a.ntiles;
+  const int p_begin = blockIdx.y * a.pairs_per_split;
+  const int p_end = min(total_pairs, p_begin + a.pairs_per_split);
+  auto pair_geom = [&](int p, int& n, int& t0) __attribute__((always_inline)) {
+    n = p / a.ntiles;
+    t0 = (p - n * a.ntiles) * FT;
+  };
+  // every wave of the workgroup executes exactly 1 + (p_end - p_begin) of these
+  auto stage_barrier = [&]() __attribute__((always_inline)) {
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+  };
+
+  if (wave >= NWC) {
+    // =============================================== producers ===============================================
+    constexpr int LPR = FT <= 2 ? 16 : 32;        // lanes per x row: (FT*V + 3) / 4 pieces of 16 bytes, V <= 32
+    constexpr int XV = CG / NWP / (64 / LPR);     // 16-byte x loads per producer thread
+    static_assert(CG % (NWP * (64 / LPR)) == 0, "x rows must tile the producer waves");
+    float rdy[DI][8];
+    f32x4 rx[XV];
+    int adj_n[2] = {-1, -1};
+    // Loads are 16 bytes wide and NOT masked: what a lane reads beyond the joints / frames it needs is a neighbouring
+    // frame or row of the same tensor (finite), and it only ever meets zeros (rows of G^T beyond V are exactly 0; frames
+    // beyond T_out and rows beyond M / C are skipped or not stored).  Only the last frame(s) of the whole tensor
+    // would read past its end: those lanes take the clamped scalar path (one wave of the grid at most).
+    const float* dy_end = a.dy + (long)a.N * a.M * Pout;
+    const float* x_end = a.in + (long)a.N * a.C * Psrc;
+    auto issue = [&](int p) __attribute__((always_inline)) {
+      int n, t0;
+      pair_geom(p, n, t0);
+      int ptid = threadIdx.x - NWC * 64;
+      asm volatile("" : "+v"(ptid));             // (see the note on laundering above)
+#pragma unroll
+      for (int k = 0; k < DI; ++k) {
+        const int item = ptid + k * NTP;         // = o*(FT*4) + f*4 + (ks*2 + hh)
+        const int o = item / (FT * 4), r = item - o * (FT * 4);
+        const int f = r >> 2, ks = (r >> 1) & 1, hh = r & 1;
+        const bool ok = (m0 + o) < a.M && (t0 + f) < a.T_out;
+        const float* src = a.dy + ((long)n * a.M + (ok ? (m0 + o) : 0)) * Pout + (long)(ok ? (t0 + f) : 0) * V +
+                           16 * ks + 4 * hh;
+        if (src + 12 <= dy_end) {
+#pragma unroll
+          for (int run = 0; run < 2; ++run) {
+            const f32x4 q = *reinterpret_cast<const f32x4_u*>(src + 8 * run);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) rdy[k][4 * run + e] = q[e];
+          }
+        } else {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            const float* q = src + (e & 3) + 8 * (e >> 2);
+            rdy[k][e] = (q < dy_end) ? *q : 0.f;
+          }
+        }
+      }
+      const int piece = ptid & (LPR - 1), rsub = (ptid & 63) / LPR;
+      const float* xb = a.in + (long)n * a.C * Psrc + (long)t0 * V + 4 * piece;
+#pragma unroll
+      for (int u = 0; u < XV; ++u) {
+        const int row = (wave - NWC) * (CG / NWP) + u * (64 / LPR) + rsub;
+        const float* src = xb + (long)min(c0 + row, a.C - 1) * Psrc;
+        if (src + 4 <= x_end) {
+          rx[u] = *reinterpret_cast<const f32x4_u*>(src);
+        } else {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) rx[u][e] = (src + e < x_end) ? src[e] : 0.f;
+        }
+      }
+    };
+    auto commit = [&](int p, unsigned char* buf) __attribute__((always_inline)) {
+      int n, t0;
+      pair_geom(p, n, t0);
+      int ptid = threadIdx.x - NWC * 64;
+      asm volatile("" : "+v"(ptid));
+      unsigned char* dyi = buf;
+      float* xs = reinterpret_cast<float*>(buf + DY_BYTES);
+#pragma unroll
+      for (int k = 0; k < DI; ++k) {
+        const int item = ptid + k * NTP;
+        const int o = item / (FT * 4), r = item - o * (FT * 4);
+        u32x4 ph, pm, pl;
+#pragma unroll
+        for (int e2 = 0; e2 < 4; ++e2) {
+          unsigned q0, q1, q2;
+          wc_split_pair(rdy[k][2 * e2], rdy[k][2 * e2 + 1], q0, q1, q2);
+          ph[e2] = q0; pm[e2] = q1; pl[e2] = q2;
+        }
+        const int slot = r * BMP + o;             // r = (f*2 + ks)*2 + hh
+        *reinterpret_cast<u32x4*>(dyi + ((0 * FT * 4) * BMP + slot) * 16) = ph;
+        *reinterpret_cast<u32x4*>(dyi + ((1 * FT * 4) * BMP + slot) * 16) = pm;
+        *reinterpret_cast<u32x4*>(dyi + ((2 * FT * 4) * BMP + slot) * 16) = pl;
+      }
+      const int piece = ptid & (LPR - 1), rsub = (ptid & 63) / LPR;
+#pragma unroll
+      for (int u = 0; u < XV; ++u) {
+        const int row = (wave - NWC) * (CG / NWP) + u * (64 / LPR) + rsub;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int q = 4 * piece + e;
+          if (q < FTV) xs[row * XP + q] = rx[u][e];
+        }
+      }
+      if (AGG && n != adj_n[p & 1]) {
+        // zero-padded adjacencies of this sample, adjp[subset][u][v] (a buffer keeps them while the sample lasts)
+        adj_n[p & 1] = n;
+        float* adjp = xs + CG * XP;
+        const float* adjn = a.adj + (long)n * 3 * V * V;
+        for (int e = ptid; e < 3 * 32 * 32; e += NTP) {
+          const int sub = e >> 10, u = (e >> 5) & 31, v = e & 31;
+          const bool ok = u < V && v < V;
+          const float tv = adjn[ok ? ((sub * V + u) * V + v) : 0];
+          adjp[e] = ok ? tv : 0.f;
+        }
+      }
+    };
+    if (XP > FTV)                                // the pad element of a row is read (times zero) by the chain
+      for (int e = threadIdx.x - NWC * 64; e < 2 * CG; e += NTP)
+        reinterpret_cast<float*>(smem + (e / CG) * BUF_BYTES + DY_BYTES)[(e % CG) * XP + FTV] = 0.f;
+    if (p_begin < p_end) {
+      issue(p_begin);
+      commit(p_begin, smem + (p_begin & 1) * BUF_BYTES);
+      if (p_begin + 1 < p_end) issue(p_begin + 1);
+    }
+    stage_barrier();
+    for (int p = p_begin; p < p_end; ++p) {
+      if (p + 1 < p_end && !(a.dbg & 2)) {
+        commit(p + 1, smem + ((p + 1) & 1) * BUF_BYTES);
+        if (p + 2 < p_end) issue(p + 2);
+      }
+      stage_barrier();
+    }
+    return;
+  }
+
+  // ================================================= consumers =================================================
+  const int lane = threadIdx.x & 63;
+  const int lr = lane & 31, h = lane >> 5;
+  const int cbw = wave % NCB, fg = (wave / NCB) % NFG, rb = wave / (NCB * NFG);
+  f32x16 acc[NS][TM];
+#pragma unroll
+  for (int sub = 0; sub < NS; ++sub)
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+      for (int j = 0; j < 16; ++j) acc[sub][tm][j] = 0.f;
+  stage_barrier();
+  for (int p = p_begin; p < p_end; ++p) {
+    int n, t0;
+    pair_geom(p, n, t0);
+    const unsigned char* dyi = smem + (p & 1) * BUF_BYTES;
+    const float* xs = reinterpret_cast<const float*>(dyi + DY_BYTES);
+    const int f = fg;
+    if (t0 + f < a.T_out && !(a.dbg & 1)) {    // wave-uniform
+      const float* xr = xs + (cbw * 32 + lr) * XP + f * V;
+      const unsigned char* ab = dyi + (((f * 4 + h) * BMP) + rb * (TM * 32) + lr) * 16;
+#pragma unroll
+      for (int sub = 0; sub < NS; ++sub) {
+        // ---- G^T[v][c] for (frame f, this wave's 32 channels, subset sub) in D layout ----
+        f32x16 d;
+        if (AGG) {
+          const float* adjp = xs + CG * XP + sub * 1024;
+          // (re-read x for every subset: kept across the subsets, these VS registers push the contraction into spills)
+          const float* xrs = xr;
+          asm volatile("" : "+v"(xrs));
+#pragma unroll
+          for (int j = 0; j < 16; ++j) d[j] = 0.f;
+          float ao[VS], xo[VS];
+#pragma unroll
+          for (int s = 0; s < VS; ++s) {
+            ao[s] = adjp[(2 * s + h) * 32 + lr];                 // A operand: A^[u = 2s+h][v = lane]
+            xo[s] = xrs[2 * s + h];          // B operand: x[c = lane][t][u = 2s+h]; u = V (odd V) reads a finite
+                                             // neighbour or the zeroed pad, and A^[u >= V] = 0
+          }
+#pragma unroll
+          for (int s = 0; s < VS; ++s) d = mfma32(ao[s], xo[s], d);
+        } else {
+#pragma unroll
+          for (int j = 0; j < 16; ++j) {
+            const int v = (j & 3) + 8 * (j >> 2) + 4 * h;
+            const float t = xr[v];             // (beyond V: a neighbour's finite value, dropped by the select)
+            d[j] = (v < V) ? t : 0.f;
+          }
+        }
+        // ---- split and contract with dy: acc[sub][tm][o][c] += sum_v dy[o][v] * G^T[v][c] ----
+        bf16x8 gb[2][3];
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+          u32x4 gh, gm, gl;
+#pragma unroll
+          for (int e2 = 0; e2 < 4; ++e2) {
+            unsigned q0, q1, q2;
+            wc_split_pair(d[8 * ks + 2 * e2], d[8 * ks + 2 * e2 + 1], q0, q1, q2);
+            gh[e2] = q0; gm[e2] = q1; gl[e2] = q2;
+          }
+          gb[ks][0] = __builtin_bit_cast(bf16x8, gh);
+          gb[ks][1] = __builtin_bit_cast(bf16x8, gm);
+          gb[ks][2] = __builtin_bit_cast(bf16x8, gl);
+        }
+        // 2*TM steps of 6 MFMAs; the dy fragments of step s+1 are read while step s runs (order pinned below)
+        auto load_a = [&](bf16x8 (&af)[3], int step) __attribute__((always_inline)) {
+          const int ks = step / TM, tm = step - ks * TM;
+#pragma unroll
+          for (int pl = 0; pl < 3; ++pl)
+            af[pl] = *reinterpret_cast<const bf16x8*>(ab + ((pl * FT * 4 + ks * 2) * BMP + tm * 32) * 16);
+        };
+        bf16x8 afc[3];
+        load_a(afc, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);
+#pragma unroll
+        for (int step = 0; step < 2 * TM; ++step) {
+          const int ks = step / TM, tm = step - ks * TM;
+          bf16x8 afn[3];
+          if (step + 1 < 2 * TM) load_a(afn, step + 1);
+          if (a.npl == 3) {
+            acc[sub][tm] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afc[2], gb[ks][0], acc[sub][tm], 0, 0, 0);
+            acc[sub][tm] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afc[0], gb[ks][2], acc[sub][tm], 0, 0, 0);
+            acc[sub][tm] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afc[1], gb[ks][1], acc[sub][tm], 0, 0, 0);
+            acc[sub][tm] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afc[1], gb[ks][0], acc[sub][tm], 0, 0, 0);
+            acc[sub][tm] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afc[0], gb[ks][1], acc[sub][tm], 0, 0, 0);
+          }
+          acc[sub][tm] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afc[0], gb[ks][0], acc[sub][tm], 0, 0, 0);
+          if (step + 1 < 2 * TM) {
+            __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl) afc[pl] = afn[pl];
+          }
+          __builtin_amdgcn_sched_group_barrier(0x008, 6, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);       // keep the subsets apart (interleaving them costs registers)
+      }
+    }
+    stage_barrier();
+  }
+  // ---- this frame group's partial slab, [z][m][c] (lanes = consecutive c: coalesced rows) ----
+  const int slab = (int)blockIdx.y * NFG + fg;
+#pragma unroll
+  for (int sub = 0; sub < NS; ++sub) {
+    float* dst = a.part + (long)slab * a.wsize + (long)sub * a.M * a.C;
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+      for (int j = 0; j < 16; ++j) {
+        const int m = m0 + (rb * TM + tm) * 32 + mfma_row(j, h);
+        const int c = c0 + cbw * 32 + lr;
+        if (m < a.M && c < a.C) dst[(long)m * a.C + c] = acc[sub][tm][j];
+      }
+  }
 }
 
 struct WcGeom {
@@ -349,6 +672,96 @@ size_t wc_slabs(int N, int M, int C, int V, int T_out) {
   return (size_t)n;
 }
 
+
+// ---- producer / consumer variant: geometry, launch, dispatch ----
+template <int AGG, int TM, int NCB, int NRB>
+WcGeom wc_geom_pc(int N, int M, int C, int V, int T_out) {
+  constexpr int BM = TM * 32 * NRB, NFG = 8 / (NCB * NRB), FT = NFG, CG = NCB * 32;
+  WcGeom g;
+  g.ntiles = (T_out + FT - 1) / FT;
+  g.ncg = (C + CG - 1) / CG;
+  g.nmb = (M + BM - 1) / BM;
+  g.XP = (FT * V) | 1;
+  g.smem_bytes = 2 * ((size_t)3 * FT * 4 * (BM + 1) * 16 + (size_t)CG * g.XP * 4 + (AGG ? 3 * 32 * 32 * 4 : 0)) + 32;
+  g.grid_x = g.nmb * g.ncg;
+  const int pairs = N * g.ntiles;
+  int want = 256 / g.grid_x;                   // one 12-wave workgroup per CU
+  if (want < 1) want = 1;
+  if (want > pairs) want = pairs;
+  g.pairs_per_split = (pairs + want - 1) / want;
+  g.nsplit = (pairs + g.pairs_per_split - 1) / g.pairs_per_split;
+  g.nslabs = g.nsplit * NFG;
+  return g;
+}
+
+template <int AGG, int TM, int NCB, int NRB, int VS>
+int wc_launch_pc(WcArgs a, void* ws, size_t ws_bytes, int* nslabs_out, hipStream_t stream) {
+  const WcGeom g = wc_geom_pc<AGG, TM, NCB, NRB>(a.N, a.M, a.C, a.V, a.T_out);
+  if (g.smem_bytes > 160 * 1024) return AGCN_ERR_UNSUPPORTED;
+  if ((size_t)g.nslabs * a.wsize * 4 > ws_bytes) return AGCN_ERR_WORKSPACE;
+  a.part = (float*)ws;
+  a.ntiles = g.ntiles; a.pairs_per_split = g.pairs_per_split; a.ncg = g.ncg; a.XP = g.XP;
+  auto kern = wgrad_pc_kernel<AGG, TM, NCB, VS, NRB>;
+  static unsigned char lds_ok[AGCN_MAX_DEVICES] = {};
+  if (int e = agcn_allow_big_lds_rt(reinterpret_cast<const void*>(kern), lds_ok)) return e;
+  AGCN_NOTE_KERNEL("wgrad_pc_kernel<%d, %d, %d, %d, %d>", AGG, TM, NCB, VS, NRB);
+  hipLaunchKernelGGL(kern, dim3(g.grid_x, g.nsplit), dim3(12 * 64), g.smem_bytes, stream, a);
+  *nslabs_out = g.nslabs;
+  return agcn_check_launch();
+}
+
+template <int AGG, int TM, int NCB, int NRB>
+int wc_dispatch_pc_vs(const WcArgs& a, void* ws, size_t ws_bytes, int* nslabs, hipStream_t s) {
+  const int vs = (a.V + 1) / 2;
+  if constexpr (!AGG) {
+    return wc_launch_pc<AGG, TM, NCB, NRB, 1>(a, ws, ws_bytes, nslabs, s);
+  } else {
+    if (vs == 13) return wc_launch_pc<AGG, TM, NCB, NRB, 13>(a, ws, ws_bytes, nslabs, s);
+    if (vs == 9) return wc_launch_pc<AGG, TM, NCB, NRB, 9>(a, ws, ws_bytes, nslabs, s);
+    return wc_launch_pc<AGG, TM, NCB, NRB, 16>(a, ws, ws_bytes, nslabs, s);
+  }
+}
+
+// AGCN_WC_PC=0 selects the single-role kernel (A/B measurement)
+static inline bool wc_pc_enabled() {
+  static int v = -1;
+  if (v < 0) {
+    const char* e = getenv("AGCN_WC_PC");
+    v = (e && atoi(e) == 0) ? 0 : 1;
+  }
+  return v == 1;
+}
+static inline bool wc_pc_applies(int C) { return wc_pc_enabled() && C % 64 == 0; }
+
+// Tiles (8 consumer waves, 2 frames per stage).  AGG: a consumer wave holds 3 subsets x 2 row tiles of accumulators:
+// 128 channels x 64 rows, or 64 channels x 128 rows.  Plain: 128 channels x 128 rows (4 row tiles per wave), or
+// 64 channels x 2 row blocks of 128.
+template <int AGG>
+int wc_dispatch_pc(const WcArgs& a, void* ws, size_t ws_bytes, int* nslabs, hipStream_t s) {
+  if constexpr (AGG) {
+    if (a.C % 128 == 0) return wc_dispatch_pc_vs<1, 2, 4, 1>(a, ws, ws_bytes, nslabs, s);
+    return wc_dispatch_pc_vs<1, 2, 2, 2>(a, ws, ws_bytes, nslabs, s);
+  } else {
+    if (a.C % 128 == 0) {
+      if (a.M > 64) return wc_dispatch_pc_vs<0, 4, 4, 1>(a, ws, ws_bytes, nslabs, s);
+      return wc_dispatch_pc_vs<0, 2, 4, 1>(a, ws, ws_bytes, nslabs, s);
+    }
+    return wc_dispatch_pc_vs<0, 2, 2, 2>(a, ws, ws_bytes, nslabs, s);
+  }
+}
+
+template <int AGG>
+size_t wc_slabs_pc(int N, int M, int C, int V, int T_out) {
+  if constexpr (AGG) {
+    if (C % 128 == 0) return (size_t)wc_geom_pc<1, 2, 4, 1>(N, M, C, V, T_out).nslabs;
+    return (size_t)wc_geom_pc<1, 2, 2, 2>(N, M, C, V, T_out).nslabs;
+  } else {
+    if (C % 128 == 0)
+      return (size_t)(M > 64 ? wc_geom_pc<0, 4, 4, 1>(N, M, C, V, T_out).nslabs : wc_geom_pc<0, 2, 4, 1>(N, M, C, V, T_out).nslabs);
+    return (size_t)wc_geom_pc<0, 2, 2, 2>(N, M, C, V, T_out).nslabs;
+  }
+}
+
 }  // namespace
 
 // C a multiple of 64, or at most 32 (one zero-padded channel block)
@@ -356,7 +769,12 @@ bool agcn_wgrad_chain_supported(int M, int C, int V) { return M >= 64 && (C % 64
 
 size_t agcn_wgrad_chain_workspace(int agg, int N, int M, int C, int V, int T_out) {
   const long wsize = (long)(agg ? 3 : 1) * M * C;
-  return (agg ? wc_slabs<1>(N, M, C, V, T_out) : wc_slabs<0>(N, M, C, V, T_out)) * (size_t)wsize * 4;
+  size_t n = agg ? wc_slabs<1>(N, M, C, V, T_out) : wc_slabs<0>(N, M, C, V, T_out);
+  if (C % 64 == 0) {                            // either variant may run (AGCN_WC_PC): size for the larger
+    const size_t m = agg ? wc_slabs_pc<1>(N, M, C, V, T_out) : wc_slabs_pc<0>(N, M, C, V, T_out);
+    if (m > n) n = m;
+  }
+  return n * (size_t)wsize * 4;
 }
 
 // writes the partial slabs into ws; *nslabs = number of slabs for the reduce kernel.  agg: x . adj_i operand, z = subset
@@ -365,8 +783,11 @@ int agcn_wgrad_chain(int agg, const float* dy, const float* x, const float* adj,
   WcArgs a = {};
   a.npl = agcn_npl();
   { const char* e = getenv("AGCN_WC_PAD"); a.pad = (e && atoi(e) == 0) ? 0 : 1; }
+  { const char* e = getenv("AGCN_WC_DBG"); a.dbg = e ? atoi(e) : 0; }
   a.dy = dy; a.in = x; a.adj = adj; a.N = N; a.M = M; a.C = C; a.V = V; a.T_src = T_src; a.T_out = T_out;
   a.stride = stride; a.wsize = (long)(agg ? 3 : 1) * M * C;
+  // (64 channels x 64 rows with aggregation: the two-row-block tile of the producer/consumer kernel would be half empty)
+  if (wc_pc_applies(C) && stride == 1 && !(agg && C % 128 != 0 && M <= 64)) return agg ? wc_dispatch_pc<1>(a, ws, ws_bytes, nslabs, s) : wc_dispatch_pc<0>(a, ws, ws_bytes, nslabs, s);
   const bool tm4 = M > 64 && C % 64 == 0;
   if (agg) return tm4 ? wc_dispatch_ncb<1, 4>(a, ws, ws_bytes, nslabs, s) : wc_dispatch_ncb<1, 2>(a, ws, ws_bytes, nslabs, s);
   return tm4 ? wc_dispatch_ncb<0, 4>(a, ws, ws_bytes, nslabs, s) : wc_dispatch_ncb<0, 2>(a, ws, ws_bytes, nslabs, s);

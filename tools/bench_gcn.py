@@ -62,4 +62,9 @@ for name in layers:
     if 'wgrad' in which:
         us = timed(lambda: ops.project_bwd_weight(dy, x, adj, Cout))
         out.append(f'wgrad {us:7.0f} us {(proj + agg) / us / 1e6:6.1f} TF')
+    if 'w1' in which:     # 1x1 weight gradient at the shape of the fused conv_a/conv_b projection (M = 6*Cout/4 rows)
+        M1 = 6 * (Cout // 4)
+        dy1 = torch.randn(N, M1, T, V, generator=g).to(dev)
+        us = timed(lambda: ops.conv_bwd_weight(dy1, x, (M1, C, 1, 1), 1))
+        out.append(f'w1 {us:7.0f} us {2.0 * M1 * C * T * V * N / us / 1e6:6.1f} TF')
     print('  '.join(out), flush=True)
