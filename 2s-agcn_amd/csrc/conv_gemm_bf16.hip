@@ -20,6 +20,7 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef f32x4 f32x4_u __attribute__((aligned(4)));     // window rows are only 4-byte aligned
 
 constexpr int CK = 16, NW = 8, NT = 512;
 
@@ -293,6 +294,276 @@ __global__ void __launch_bounds__(NT, (TAPS == 1 && TM == 2 && TN == 1) ? 4 : 2)
   epilogue_rows<BM, NW, 4 * TN>(ep, tile, TP, bias_s, red, a.M, m0, rows0, Pfull, nvalid, poff, (long)n * a.ntiles + tile_id);
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Producer / consumer variant with a weight ring (128-row blocks, stride-1 windows, K a multiple of 16).
+// Measured on the kernel above (l9 shape): 0.20 of 1.44 ms is staging that no MFMA overlaps (all eight waves write the
+// 110 KB weight image + the split window between two barriers), another 0.18 the matrix loop's own stalls.  Here
+//   * 8 consumer waves only read fragments and issue MFMAs: wave w owns 32 positions x 128 rows, one (chunk, tap)
+//     step = 24 MFMAs, the fragments of step g+1 are read while step g runs;
+//   * 4 producer waves feed them: the packed weight image of one (chunk, tap) step is ONE contiguous 12 KB slot that
+//     goes global -> LDS by LDS-DMA (no registers, no VALU, no ds_write) into a ring of R slots, R-2 steps ahead of its
+//     use; the source window of the next 16-channel chunk is loaded 16 bytes per lane, split into bf16 planes and
+//     written to the other of two window buffers.
+// Only the producers have vector-memory operations in flight, so the consumers' LDS reads never wait on a vmcnt.
+// One barrier per step.  The ring slot of step g is (g mod R).
+template <int TAPS, int NPL, int R, int NWP = 4>
+__global__ void __launch_bounds__((8 + NWP) * 64, 3) conv_pc_kernel(const BfArgs a) {
+  constexpr int TM = 4, BM = 128, NWC = 8, NTALL = (NWC + NWP) * 64, NTP = NWP * 64;
+  constexpr int SLOT = NPL * 2 * BM * 16;               // bytes of one step's weight image [plane][h][m][8]
+  constexpr int PIECES = SLOT / 1024;                   // 1 KB LDS-DMA pieces per slot
+  constexpr int PPW = (PIECES + NWP - 1) / NWP;         // pieces per producer wave
+  constexpr int NMF = NPL == 3 ? 6 : NPL == 2 ? 3 : 1;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  unsigned char* ring = smem;
+  const int WLR = a.WLR, V = a.V;
+  const int B_BYTES = NPL * 2 * WLR * 16;
+  unsigned char* Bbase = smem + a.off_b;
+
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  const int bid = xcd_remap(blockIdx.x, gridDim.x);
+  const int mbk = bid % a.nmb;
+  const int nt_id = bid / a.nmb;
+  const int n = nt_id / a.ntiles, tile_id = nt_id - n * a.ntiles;
+  const int m0 = mbk * BM;
+  const int tt = a.tt, t0 = tile_id * tt;
+  const int ttv = tt * V;
+  const int nvalid = min(tt, a.T_out - t0) * V;
+  const int Psrc = a.T_src * V;
+  const int g0 = (t0 + a.f_off) * V;                    // first window position (may be negative: zero padding)
+  const int WL = a.FW * V;
+  const int nchunks = a.nchunks;
+  const int G = nchunks * TAPS;
+
+  float* bias_s = reinterpret_cast<float*>(smem + a.off_bias);
+  for (int e = threadIdx.x; e < BM; e += NTALL) bias_s[e] = (a.bias && m0 + e < a.M) ? a.bias[m0 + e] : 0.f;
+
+  auto step_barrier = [&]() __attribute__((always_inline)) {
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+  };
+
+  if (wave >= NWC) {
+    // =============================================== producers ===============================================
+    const int pw = wave - NWC;
+    typedef const __attribute__((address_space(1))) void* gptr_t;
+    typedef __attribute__((address_space(3))) void* lptr_t;
+    const unsigned char* wsrc = reinterpret_cast<const unsigned char*>(a.wp) + (long)mbk * G * SLOT + lane * 16;
+    auto dma_slot = [&](int g) __attribute__((always_inline)) {   // step g -> ring slot g % R (all lanes, uniform g)
+      const unsigned char* src = wsrc + (long)g * SLOT;
+      unsigned char* dst = ring + (g % R) * SLOT;
+#pragma unroll
+      for (int u = 0; u < PPW; ++u) {
+        const int piece = pw + u * NWP;
+        if (piece < PIECES)
+          __builtin_amdgcn_global_load_lds((gptr_t)(src + piece * 1024), (lptr_t)(dst + piece * 1024), 16, 0, 0);
+      }
+    };
+    // window staging: lane task = (channel half hb, 4 consecutive window rows): 2 * ceil(WL / 4) tasks over 256 threads
+    const int ptid = threadIdx.x - NWC * 64;
+    const int npiece = (WL + 3) >> 2;
+    const int ntask = 2 * npiece;
+    constexpr int TK = 256 / NTP;                        // tasks per thread (2 * 128 pieces: windows up to 512 rows)
+    f32x4 rb[TK][8];
+    auto issue_B = [&](int ch) __attribute__((always_inline)) {
+#pragma unroll
+      for (int k = 0; k < TK; ++k) {
+        if (k * NTP >= ntask) continue;                  // uniform
+        int task = ptid + k * NTP;
+        if (task >= ntask) task = ntask - 1;             // duplicates rewrite identical data
+        const int hb = task & 1, r0 = (task >> 1) * 4;
+        const int gp = g0 + r0;
+        const float* src = a.in + ((long)n * a.in_rows + ch * CK + hb * 8) * Psrc + gp;
+        if (gp >= 0 && gp + 3 < Psrc) {
+#pragma unroll
+          for (int c = 0; c < 8; ++c) rb[k][c] = *reinterpret_cast<const f32x4_u*>(src + (long)c * Psrc);
+        } else {                                          // sample edge: the temporal zero padding
+#pragma unroll
+          for (int c = 0; c < 8; ++c)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              const bool ok = gp + e >= 0 && gp + e < Psrc;
+              const float t = src[(long)c * Psrc + (ok ? e : -gp)];
+              rb[k][c][e] = ok ? t : 0.f;
+            }
+        }
+      }
+    };
+    auto commit_B = [&](unsigned char* Bb) __attribute__((always_inline)) {
+#pragma unroll
+      for (int k = 0; k < TK; ++k) {
+        if (k * NTP >= ntask) continue;
+        int task = ptid + k * NTP;
+        if (task >= ntask) task = ntask - 1;
+        const int hb = task & 1, r0 = (task >> 1) * 4;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          u32x4 ph, pm, pl;
+#pragma unroll
+          for (int c = 0; c < 4; ++c) {
+            unsigned q0, q1, q2;
+            split_pair(rb[k][2 * c][e], rb[k][2 * c + 1][e], q0, q1, q2);
+            ph[c] = q0; pm[c] = q1; pl[c] = q2;
+          }
+          const int r = r0 + e;
+          if (r < WLR) {
+            *reinterpret_cast<u32x4*>(Bb + ((0 * 2 + hb) * WLR + r) * 16) = ph;
+            if (NPL >= 2) *reinterpret_cast<u32x4*>(Bb + ((1 * 2 + hb) * WLR + r) * 16) = pm;
+            if (NPL == 3) *reinterpret_cast<u32x4*>(Bb + ((2 * 2 + hb) * WLR + r) * 16) = pl;
+          }
+        }
+      }
+    };
+    // prologue: ring slots of steps 0 .. R-2, window of chunk 0
+#pragma unroll
+    for (int g = 0; g < R - 1; ++g)
+      if (g < G) dma_slot(g);
+    issue_B(0);
+    commit_B(Bbase);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    step_barrier();
+    int g = 0;
+    for (int ch = 0; ch < nchunks; ++ch) {
+#pragma unroll
+      for (int tap = 0; tap < TAPS; ++tap, ++g) {
+        if (a.dbg & 2) { step_barrier(); continue; }
+        if (g + R - 1 < G && !(a.dbg & 8)) dma_slot(g + R - 1);   // into the slot of step g-1, free since the last barrier
+        if (TAPS >= 3) {
+          if (tap == 0 && ch + 1 < nchunks && !(a.dbg & 4)) issue_B(ch + 1);
+          if (tap == (TAPS >= 6 ? TAPS - 3 : TAPS - 2) && ch + 1 < nchunks && !(a.dbg & 4))
+            commit_B(Bbase + ((ch + 1) & 1) * B_BYTES);  // loads had TAPS-3 steps to land; readers start at tap TAPS-1
+        } else {
+          if (tap == 0 && ch + 1 < nchunks) { issue_B(ch + 1); commit_B(Bbase + ((ch + 1) & 1) * B_BYTES); }
+        }
+        // the slot of step g+2 is read from the next barrier on: at most the R-3 newer slots may still be in flight
+        asm volatile("s_waitcnt vmcnt(%0)" :: "n"(PPW * (R - 3)) : "memory");
+        step_barrier();
+      }
+    }
+    return;
+  }
+
+  // ================================================= consumers =================================================
+  const int lr = lane & 31, h = lane >> 5;
+  int q = wave * 32 + lr;
+  if (q >= ttv) q = 0;
+  const int boff = q;                                    // stride-1 window: position q of the tile = window row q (+tap*V)
+  f32x16 acc[TM];
+#pragma unroll
+  for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+    for (int j = 0; j < 16; ++j) acc[tm][j] = 0.f;
+
+  const unsigned char* a_lane = ring + (h * BM + lr) * 16;
+  auto load_a = [&](bf16x8 (&af)[NPL], int slot, int tm) __attribute__((always_inline)) {
+#pragma unroll
+    for (int pl = 0; pl < NPL; ++pl)
+      af[pl] = *reinterpret_cast<const bf16x8*>(a_lane + slot * SLOT + (pl * 2 * BM + tm * 32) * 16);
+  };
+  auto load_b = [&](bf16x8 (&bf)[NPL], const unsigned char* Bb, int tap) __attribute__((always_inline)) {
+#pragma unroll
+    for (int pl = 0; pl < NPL; ++pl)
+      bf[pl] = *reinterpret_cast<const bf16x8*>(Bb + ((pl * 2 + h) * WLR + boff + tap * V) * 16);
+  };
+  step_barrier();                                        // ring slots 0 .. R-2 and window 0 are in place
+  bf16x8 afc[NPL], bfc[NPL];
+  load_b(bfc, Bbase, 0);
+  load_a(afc, 0, 0);
+  int slot = 0;                                          // g % R
+  for (int ch = 0; ch < nchunks; ++ch) {
+    const unsigned char* Bb = Bbase + (ch & 1) * B_BYTES;
+    const unsigned char* Bn = Bbase + ((ch + 1) & 1) * B_BYTES;
+#pragma unroll
+    for (int tap = 0; tap < TAPS; ++tap) {
+      const int slot_n = (slot + 1 == R) ? 0 : slot + 1;
+      if (a.dbg & 1) { step_barrier(); continue; }
+      bf16x8 bfn[NPL];
+#pragma unroll
+      for (int tm = 0; tm < TM; ++tm) {
+        bf16x8 afn[NPL];
+        if (tm + 1 < TM) {
+          load_a(afn, slot, tm + 1);
+        } else {
+          // first fragments of the next step (the last step re-reads a valid slot; unused)
+          load_a(afn, slot_n, 0);
+          if (tap + 1 < TAPS) load_b(bfn, Bb, tap + 1);
+          else load_b(bfn, Bn, 0);
+        }
+        if (NPL == 3) {
+          acc[tm] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afc[NPL - 1], bfc[0], acc[tm], 0, 0, 0);
+          acc[tm] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afc[0], bfc[NPL - 1], acc[tm], 0, 0, 0);
+          acc[tm] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afc[NPL >= 2 ? 1 : 0], bfc[NPL >= 2 ? 1 : 0], acc[tm], 0, 0, 0);
+        }
+        if (NPL >= 2) {
+          acc[tm] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afc[NPL >= 2 ? 1 : 0], bfc[0], acc[tm], 0, 0, 0);
+          acc[tm] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afc[0], bfc[NPL >= 2 ? 1 : 0], acc[tm], 0, 0, 0);
+        }
+        acc[tm] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afc[0], bfc[0], acc[tm], 0, 0, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, NPL, 0);
+        if (tm + 1 == TM) __builtin_amdgcn_sched_group_barrier(0x100, NPL, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, NMF, 0);
+#pragma unroll
+        for (int pl = 0; pl < NPL; ++pl) afc[pl] = afn[pl];
+      }
+#pragma unroll
+      for (int pl = 0; pl < NPL; ++pl) bfc[pl] = bfn[pl];
+      slot = slot_n;
+      step_barrier();
+    }
+  }
+
+  // ---- epilogue (epilogue.h), consumers only: the producers have left, the barriers count the live waves ----
+  float* tile = reinterpret_cast<float*>(smem);        // [BM][TP]
+  const int TP = NWC * 32 + 1;
+  float* red = tile + BM * TP;                         // [512 * 2]
+#pragma unroll
+  for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+    for (int j = 0; j < 16; ++j) tile[(tm * 32 + mfma_row(j, h)) * TP + wave * 32 + lr] = acc[tm][j];
+  __syncthreads();
+  int poff[4];
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    const int q2 = lane + 64 * u;
+    const int tl2 = q2 / V;
+    poff[u] = tl2 * a.out_fs * V + (q2 - tl2 * V);
+  }
+  EpiPtrs ep;
+  ep.out = a.out; ep.add1 = a.add1; ep.mask1 = a.mask1; ep.add2 = a.add2; ep.mask2 = a.mask2; ep.stats = a.stats;
+  ep.accumulate = a.accumulate;
+  const long Pfull = (long)a.T_full * V;
+  const long rows0 = (long)n * a.M * Pfull + ((long)t0 * a.out_fs + a.out_fo) * V;
+  epilogue_rows<BM, NWC, 4>(ep, tile, TP, bias_s, red, a.M, m0, rows0, Pfull, nvalid, poff, (long)n * a.ntiles + tile_id);
+}
+
+// slot-major weight images for conv_pc_kernel: wp[(mb*nchunks + ch)*TAPS + tap][plane][h][ml][8]
+template <int TAPS, int BM, int NPL>
+__global__ void __launch_bounds__(256) pack_weights_slots_kernel(const BfPackArgs p) {
+  constexpr int PLANE = 2 * BM * 8;                    // bf16 elements of one plane of a slot
+  const int tap = blockIdx.x % TAPS;
+  const int ch = (blockIdx.x / TAPS) % p.nchunks, mb = blockIdx.x / (TAPS * p.nchunks);
+  unsigned short* dst = p.wp + (long)blockIdx.x * NPL * PLANE;
+  const int gt = p.tap_flip_from >= 0 ? (p.tap_flip_from - (tap * p.tap_mul + p.tap_add)) : tap;
+  for (int e = threadIdx.x; e < PLANE / 2; e += 256) {
+    const int j = (e & 3) * 2;
+    const int ml = (e >> 2) % BM;
+    const int h = (e >> 2) / BM;
+    const int m = mb * BM + ml;
+    float v[2];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      const int kc = ch * CK + h * 8 + j + q;
+      v[q] = (m < p.M && kc < p.Kinner) ? p.w[(long)m * p.sa_m + (long)kc * p.sa_c + gt] : 0.f;
+    }
+    unsigned ph, pm, pl;
+    split_pair(v[0], v[1], ph, pm, pl);
+    const int o = (h * BM + ml) * 8 + j;
+    *reinterpret_cast<unsigned*>(dst + 0 * PLANE + o) = ph;
+    if (NPL >= 2) *reinterpret_cast<unsigned*>(dst + 1 * PLANE + o) = pm;
+    if (NPL == 3) *reinterpret_cast<unsigned*>(dst + 2 * PLANE + o) = pl;
+  }
+}
+
 struct BfGeom {
   int tt, ntiles, FW, WLR, nchunks, nmb, off_b, off_bias;
   size_t smem_bytes, pack_bytes;
@@ -360,17 +631,95 @@ int launch_bf(BfProblem& p, hipStream_t stream) {
   return agcn_check_launch();
 }
 
+
+// ---- producer / consumer ring variant: geometry + launch ----
+template <int TAPS, int NPL, int R>
+BfGeom bf_geometry_pc(int V, int T_out, int M, int Kinner) {
+  constexpr int BM = 128, SLOT = NPL * 2 * BM * 16;
+  BfGeom g;
+  g.tt = 256 / V;
+  if (g.tt > T_out) g.tt = T_out;
+  if (g.tt < 1) g.tt = 1;
+  g.ntiles = (T_out + g.tt - 1) / g.tt;
+  g.FW = (g.tt - 1) + TAPS;
+  g.WLR = g.FW * V + 8;
+  g.nchunks = (Kinner + CK - 1) / CK;
+  g.nmb = (M + BM - 1) / BM;
+  g.off_b = R * SLOT;
+  const size_t main_b = (size_t)g.off_b + 2 * (size_t)NPL * 2 * g.WLR * 16;
+  const size_t epi_b = (size_t)BM * (8 * 32 + 1) * 4 + (size_t)512 * 2 * 4;
+  g.smem_bytes = ((main_b > epi_b ? main_b : epi_b) + 15) & ~(size_t)15;
+  g.off_bias = (int)g.smem_bytes;
+  g.smem_bytes += (size_t)BM * 4;
+  g.pack_bytes = (size_t)g.nmb * g.nchunks * TAPS * SLOT;
+  return g;
+}
+
+// AGCN_CONV_PC=0 selects the single-role kernel (A/B measurement)
+static inline bool conv_pc_enabled() {
+  static int v = -1;
+  if (v < 0) {
+    const char* e = getenv("AGCN_CONV_PC");
+    v = (e && atoi(e) == 0) ? 0 : 1;
+  }
+  return v == 1;
+}
+
+template <int TAPS, int NPL, int R = 5, int NWP = 4>
+int launch_pc(BfProblem& p, hipStream_t stream) {
+  constexpr int BM = 128;
+  BfArgs a = p.a;
+  const BfGeom g = bf_geometry_pc<TAPS, NPL, R>(a.V, a.T_out, a.M, a.Kinner);
+  if (g.smem_bytes > 160 * 1024) return AGCN_ERR_UNSUPPORTED;
+  if (g.pack_bytes > p.ws_bytes) return AGCN_ERR_WORKSPACE;
+  a.tt = g.tt; a.ntiles = g.ntiles; a.FW = g.FW; a.WLR = g.WLR; a.nchunks = g.nchunks; a.nmb = g.nmb;
+  a.off_b = g.off_b; a.off_bias = g.off_bias;
+  a.wp = (const unsigned short*)p.ws;
+  BfPackArgs pk;
+  pk.w = p.w; pk.wp = (unsigned short*)p.ws; pk.M = a.M; pk.Kinner = a.Kinner; pk.nchunks = g.nchunks;
+  pk.sa_m = p.sa_m; pk.sa_c = p.sa_c;
+  pk.tap_mul = p.tap_mul; pk.tap_add = p.tap_add; pk.tap_flip_from = p.tap_flip_from;
+  hipLaunchKernelGGL((pack_weights_slots_kernel<TAPS, BM, NPL>), dim3(g.nmb * g.nchunks * TAPS), dim3(256), 0, stream, pk);
+  int rc = agcn_check_launch();
+  if (rc) return rc;
+  auto kern = conv_pc_kernel<TAPS, NPL, R, NWP>;
+  static unsigned char lds_ok[AGCN_MAX_DEVICES] = {};
+  if (int e = agcn_allow_big_lds_rt(reinterpret_cast<const void*>(kern), lds_ok)) return e;
+  static const int dbg = getenv("AGCN_CB_DBG") ? atoi(getenv("AGCN_CB_DBG")) : 0;
+  a.dbg = dbg;
+  AGCN_NOTE_KERNEL("conv_pc_kernel<%d, %d, %d, %d>", TAPS, NPL, R, NWP);
+  hipLaunchKernelGGL(kern, dim3((unsigned)(a.N * g.ntiles * g.nmb)), dim3((8 + NWP) * 64), g.smem_bytes, stream, a);
+  return agcn_check_launch();
+}
+
+template <int TAPS>
+bool pc_applies(const BfProblem& p, int npl) {
+  if (!conv_pc_enabled() || TAPS < 3 || npl != 3) return false;
+  if (p.a.M % 128 != 0 || p.a.Kinner % CK != 0 || p.a.src_stride != 1 || p.a.V > 32) return false;
+  const BfGeom g = bf_geometry_pc<TAPS, 3, 5>(p.a.V, p.a.T_out, p.a.M, p.a.Kinner);
+  return g.smem_bytes <= 160 * 1024 && g.FW * p.a.V <= 512;
+}
+
 // 128-row blocks (4 m-tiles per wave) when M allows it: the staged+split window is reused by twice the MFMAs
 template <int TAPS, int WQ>
 int launch_npl(BfProblem& p, int npl, hipStream_t s) {
   const bool fits128 = bf_geometry<TAPS, 128>(p.a.V, p.a.T_out, p.a.src_stride, p.a.M, p.a.Kinner).smem_bytes <=
                        160 * 1024;
+  if constexpr (TAPS >= 3) {
+    if (pc_applies<TAPS>(p, npl)) {
+      static const int nwp2 = getenv("AGCN_CONV_NWP2") ? atoi(getenv("AGCN_CONV_NWP2")) : 0;
+      if (nwp2) return launch_pc<TAPS, 3, 5, 2>(p, s);
+      return launch_pc<TAPS, 3>(p, s);
+    }
+  }
   if (p.a.M % 128 == 0 && fits128) {
     if (npl == 1) return launch_bf<TAPS, 1, WQ, 4>(p, s);
     return npl == 2 ? launch_bf<TAPS, 2, WQ, 4>(p, s) : launch_bf<TAPS, 3, WQ, 4>(p, s);
   }
-  if (agcn_bf16_conv_wide(TAPS, p.a.M) && npl == 3) return launch_bf<TAPS, 3, 3, 2, 2>(p, s);
-  if (agcn_bf16_conv_wide(TAPS, p.a.M) && npl == 1) return launch_bf<TAPS, 1, 3, 2, 2>(p, s);
+  if (agcn_bf16_conv_wide(TAPS, p.a.M) && (npl == 3 || npl == 1)) {   // (a window too long for the wide tile: narrow one)
+    const int rc = npl == 3 ? launch_bf<TAPS, 3, 3, 2, 2>(p, s) : launch_bf<TAPS, 1, 3, 2, 2>(p, s);
+    if (rc != AGCN_ERR_UNSUPPORTED) return rc;
+  }
   if (npl == 1) return launch_bf<TAPS, 1, WQ, 2>(p, s);
   return npl == 2 ? launch_bf<TAPS, 2, WQ, 2>(p, s) : launch_bf<TAPS, 3, WQ, 2>(p, s);
 }
