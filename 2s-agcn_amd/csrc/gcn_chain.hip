@@ -45,6 +45,7 @@ struct ChainArgs {
   int XP;                      // pitch (floats) of an x chunk row in LDS (odd)
   int off_bias;                // byte offset of the bias row in LDS
   int npl;                     // 3: six split products (bf16x6) ; 1: hi*hi only (bf16)
+  int dbg;                     // profiling switches (AGCN_GC_DBG): 1 = no matrix work, 2 = no staging after the prologue
 };
 
 struct ChainPackArgs {
@@ -118,10 +119,17 @@ __global__ void __launch_bounds__(NW * 64, 2) gcn_chain_kernel(const ChainArgs a
   constexpr int XB = FT / 2;                           // 64-float column blocks of a staged x row (V <= 32)
   constexpr int XR = CB / NW;                          // x rows per wave
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  float* adjp = reinterpret_cast<float*>(smem);                       // [3][32][32]
-  float* xb = adjp + 3 * 32 * 32;                                     // [CB][XP]
-  const int xb_bytes = ((CB * a.XP * 4 + 15) & ~15);
-  unsigned char* abuf = smem + 3 * 32 * 32 * 4 + xb_bytes;            // [2][A_IMG]
+  // VS == 0: the aggregation runs on split-bf16 MFMA too (K = 32 joints = two 16-deep steps, 12 MFMAs of 32 cycles
+  // instead of 13 exact-f32 steps of 64): the adjacencies are kept as bf16 planes [i][plane][ks][h][v][8 u], a lane's
+  // x fragment (8 consecutive joints of its channel) is split in registers once per channel block and serves all
+  // three subsets.
+  constexpr bool BCH = (VS == 0);
+  constexpr int ADJ_BYTES = BCH ? 3 * 3 * 2 * 2 * 32 * 16 : 3 * 32 * 32 * 4;
+  float* adjp = reinterpret_cast<float*>(smem);                       // [3][32][32] (f32 chain)
+  unsigned char* adjq = smem;                                         // bf16 planes (split chain)
+  float* xb = reinterpret_cast<float*>(smem + ADJ_BYTES);             // [CB][XP] (+ 8 floats of slack when BCH)
+  const int xb_bytes = ((CB * a.XP * 4 + (BCH ? 32 : 0) + 15) & ~15);
+  unsigned char* abuf = smem + ADJ_BYTES + xb_bytes;                  // [2][A_IMG]
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -146,7 +154,7 @@ __global__ void __launch_bounds__(NW * 64, 2) gcn_chain_kernel(const ChainArgs a
   for (int e = tid; e < BM; e += NT) bias_s[e] = (a.bias && m0 + e < a.M) ? a.bias[m0 + e] : 0.f;
 
   // ---- the sample's adjacencies, zero padded to 32x32 (rows u >= V are zero: clamped x operands need no mask) ----
-  {
+  if (!BCH) {
     const float* adjn = a.adj + (long)n * 3 * V * V;
     for (int e = tid; e < 3 * 32 * 32; e += NT) {
       const int i = e >> 10, u = (e >> 5) & 31, col = e & 31;
@@ -155,6 +163,28 @@ __global__ void __launch_bounds__(NW * 64, 2) gcn_chain_kernel(const ChainArgs a
       const float tv = adjn[gi];
       adjp[e] = ok ? tv : 0.f;
     }
+  } else {
+    // B[u][v] of subset i as the B operand of v_mfma_f32_32x32x16_bf16: lane (h, v) holds u = 16 ks + 8 h + e
+    const float* adjn = a.adj + (long)n * 3 * V * V;
+    for (int e = tid; e < 3 * 2 * 2 * 32 * 4; e += NT) {             // one pair (u, u+1) per iteration
+      const int e2 = e & 3, col = (e >> 2) & 31, hh = (e >> 7) & 1, ks = (e >> 8) & 1, i = e >> 9;
+      float v[2];
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        const int u = 16 * ks + 8 * hh + 2 * e2 + q;
+        const bool ok = u < V && col < V;
+        const int gi = ok ? (a.adj_t ? ((i * V + col) * V + u) : ((i * V + u) * V + col)) : 0;
+        const float tv = adjn[gi];
+        v[q] = ok ? tv : 0.f;
+      }
+      unsigned p0, p1, p2;
+      split_pair(v[0], v[1], p0, p1, p2);
+      const int o = (((ks * 2 + hh) * 32) + col) * 16 + e2 * 4;     // within one (i, plane) image of 2048 bytes
+      *reinterpret_cast<unsigned*>(adjq + (i * 3 + 0) * 2048 + o) = p0;
+      *reinterpret_cast<unsigned*>(adjq + (i * 3 + 1) * 2048 + o) = p1;
+      *reinterpret_cast<unsigned*>(adjq + (i * 3 + 2) * 2048 + o) = p2;
+    }
+    if (tid < 8) xb[CB * XP + tid] = 0.f;                            // slack behind the last chunk row
   }
 
   f32x16 acc[TM];
@@ -162,6 +192,7 @@ __global__ void __launch_bounds__(NW * 64, 2) gcn_chain_kernel(const ChainArgs a
   for (int tm = 0; tm < TM; ++tm)
 #pragma unroll
     for (int j = 0; j < 16; ++j) acc[tm][j] = 0.f;
+  if (XP > FT * V && tid < CB) xb[tid * XP + FT * V] = 0.f;   // the pad element of a chunk row is read (times zero)
 
   // ---- prefetch registers (raw loads; predicates are re-evaluated at commit) ----
   u32x4 ra[EA];
@@ -218,7 +249,8 @@ __global__ void __launch_bounds__(NW * 64, 2) gcn_chain_kernel(const ChainArgs a
   if (S > 1) issue_A(1);
   __syncthreads();
 
-  float xo[VS];
+  float xo[BCH ? 1 : VS];
+  bf16x8 xq[2][3];                                     // split chain: this lane's x fragments (ks, plane)
   for (int s = 0; s < S; ++s) {
     const bool plain = s >= S1;
     const int cb = plain ? 0 : s / 3, i = plain ? 0 : s - cb * 3;
@@ -235,32 +267,68 @@ __global__ void __launch_bounds__(NW * 64, 2) gcn_chain_kernel(const ChainArgs a
       if (s + 1 < S) commit_A(s + 1);
       if (s + 2 < S) issue_A(s + 2);
       if (chunk + 2 < nchunks) issue_X(chunk + 2);
-    } else {
+    } else if (!(a.dbg & 2)) {
       if (s + 1 < S) commit_A(s + 1);                    // loads were issued one stage ago
       if (i == 2 && cb + 1 < nchunks) commit_X(cb + 1);  // xb is free: every wave took its operands at i == 0
       if (s + 2 < S) issue_A(s + 2);
       if (i == 0 && cb + 1 < nchunks) issue_X(cb + 1);
       if (i == 2 && cb + 1 == a.ncb && cb + 2 < nchunks) issue_X(cb + 2);   // second plain chunk: one stage ahead
     }
-    if (fvalid) {
+    if (fvalid && !(a.dbg & 1)) {
       if (!plain) {
         // ---- 1. G = X[cb] . A^_i for this wave's frame ----
         const float* xr = xb + lr * XP + wave * V;
-        const float* ar = adjp + i * 1024 + lr;
 #pragma unroll
         for (int j = 0; j < 16; ++j) d[j] = 0.f;
-        if (i == 0) {
+        if constexpr (!BCH) {
+          const float* ar = adjp + i * 1024 + lr;
+          if (i == 0) {
 #pragma unroll
-          for (int k = 0; k < VS; ++k) xo[k] = xr[min(2 * k + h, V - 1)];
+            for (int k = 0; k < VS; ++k) xo[k] = xr[2 * k + h];   // u = V (odd V): a finite neighbour or the zeroed pad, times 0
+          }
+          float bo[BCH ? 1 : VS];
+#pragma unroll
+          for (int k = 0; k < VS; ++k) bo[k] = ar[(2 * k + h) * 32];
+#pragma unroll
+          for (int k = 0; k < VS; ++k) d = mfma32(xo[k], bo[k], d);
+        } else {
+          if (i == 0) {
+            // joints 16 ks + 8 h + e of channel lr; beyond V: finite neighbours (next frame / row / zeroed slack) that
+            // meet the zero rows of the adjacency
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+              u32x4 qh, qm, ql;
+#pragma unroll
+              for (int e2 = 0; e2 < 4; ++e2) {
+                unsigned p0, p1, p2;
+                split_pair(xr[16 * ks + 8 * h + 2 * e2], xr[16 * ks + 8 * h + 2 * e2 + 1], p0, p1, p2);
+                qh[e2] = p0; qm[e2] = p1; ql[e2] = p2;
+              }
+              xq[ks][0] = __builtin_bit_cast(bf16x8, qh);
+              xq[ks][1] = __builtin_bit_cast(bf16x8, qm);
+              xq[ks][2] = __builtin_bit_cast(bf16x8, ql);
+            }
+          }
+          const unsigned char* aq = adjq + i * 3 * 2048 + (h * 32 + lr) * 16;
+#pragma unroll
+          for (int ks = 0; ks < 2; ++ks) {
+            const bf16x8 b0 = *reinterpret_cast<const bf16x8*>(aq + 0 * 2048 + ks * 1024);
+            const bf16x8 b1 = *reinterpret_cast<const bf16x8*>(aq + 1 * 2048 + ks * 1024);
+            const bf16x8 b2 = *reinterpret_cast<const bf16x8*>(aq + 2 * 2048 + ks * 1024);
+            if (a.npl == 3) {
+              d = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xq[ks][2], b0, d, 0, 0, 0);
+              d = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xq[ks][0], b2, d, 0, 0, 0);
+              d = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xq[ks][1], b1, d, 0, 0, 0);
+              d = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xq[ks][1], b0, d, 0, 0, 0);
+              d = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xq[ks][0], b1, d, 0, 0, 0);
+            }
+            d = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xq[ks][0], b0, d, 0, 0, 0);
+          }
         }
-        float bo[VS];
-#pragma unroll
-        for (int k = 0; k < VS; ++k) bo[k] = ar[(2 * k + h) * 32];
-#pragma unroll
-        for (int k = 0; k < VS; ++k) d = mfma32(xo[k], bo[k], d);
       }
       // ---- 2. split G in registers and project: acc[tm] += W_i[:, cb] . G ----
       const unsigned char* ab = abuf + (s & 1) * A_IMG + lane * 16;
+      bf16x8 gb[2][3];
 #pragma unroll
       for (int hf = 0; hf < 2; ++hf) {
         u32x4 gh, gm, gl;
@@ -270,23 +338,41 @@ __global__ void __launch_bounds__(NW * 64, 2) gcn_chain_kernel(const ChainArgs a
           split_pair(d[8 * hf + 2 * e2], d[8 * hf + 2 * e2 + 1], p0, p1, p2);
           gh[e2] = p0; gm[e2] = p1; gl[e2] = p2;
         }
-        const bf16x8 b0 = __builtin_bit_cast(bf16x8, gh), b1 = __builtin_bit_cast(bf16x8, gm),
-                     b2 = __builtin_bit_cast(bf16x8, gl);
+        gb[hf][0] = __builtin_bit_cast(bf16x8, gh);
+        gb[hf][1] = __builtin_bit_cast(bf16x8, gm);
+        gb[hf][2] = __builtin_bit_cast(bf16x8, gl);
+      }
+      // 2*TM steps of 6 MFMAs; the weight fragments of step k+1 are read while step k runs (order pinned below: the
+      // scheduler otherwise sinks every read to its use and waits for it)
+      auto load_w = [&](bf16x8 (&af)[3], int step) __attribute__((always_inline)) {
+        const int hf = step / TM, tm = step - hf * TM;
 #pragma unroll
-        for (int tm = 0; tm < TM; ++tm) {
-          const bf16x8 a0 = *reinterpret_cast<const bf16x8*>(ab + ((0 * 2 + hf) * TM + tm) * 1024);
-          const bf16x8 a1 = *reinterpret_cast<const bf16x8*>(ab + ((1 * 2 + hf) * TM + tm) * 1024);
-          const bf16x8 a2 = *reinterpret_cast<const bf16x8*>(ab + ((2 * 2 + hf) * TM + tm) * 1024);
-          // smallest products first; npl == 1 (AGCN_GEMM=bf16): the hi*hi product only
-          if (a.npl == 3) {
-            acc[tm] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, b0, acc[tm], 0, 0, 0);
-            acc[tm] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b2, acc[tm], 0, 0, 0);
-            acc[tm] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b1, acc[tm], 0, 0, 0);
-            acc[tm] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b0, acc[tm], 0, 0, 0);
-            acc[tm] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b1, acc[tm], 0, 0, 0);
-          }
-          acc[tm] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b0, acc[tm], 0, 0, 0);
+        for (int pl = 0; pl < 3; ++pl)
+          af[pl] = *reinterpret_cast<const bf16x8*>(ab + ((pl * 2 + hf) * TM + tm) * 1024);
+      };
+      bf16x8 afc[3];
+      load_w(afc, 0);
+      __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);
+#pragma unroll
+      for (int step = 0; step < 2 * TM; ++step) {
+        const int hf = step / TM, tm = step - hf * TM;
+        bf16x8 afn[3];
+        if (step + 1 < 2 * TM) load_w(afn, step + 1);
+        // smallest products first; npl == 1 (AGCN_GEMM=bf16): the hi*hi product only
+        if (a.npl == 3) {
+          acc[tm] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afc[2], gb[hf][0], acc[tm], 0, 0, 0);
+          acc[tm] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afc[0], gb[hf][2], acc[tm], 0, 0, 0);
+          acc[tm] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afc[1], gb[hf][1], acc[tm], 0, 0, 0);
+          acc[tm] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afc[1], gb[hf][0], acc[tm], 0, 0, 0);
+          acc[tm] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afc[0], gb[hf][1], acc[tm], 0, 0, 0);
         }
+        acc[tm] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afc[0], gb[hf][0], acc[tm], 0, 0, 0);
+        if (step + 1 < 2 * TM) {
+          __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);
+#pragma unroll
+          for (int pl = 0; pl < 3; ++pl) afc[pl] = afn[pl];
+        }
+        __builtin_amdgcn_sched_group_barrier(0x008, 6, 0);
       }
     }
     __syncthreads();
@@ -386,7 +472,7 @@ struct ChainGeom {
 };
 
 template <int TM, int NW>
-ChainGeom chain_geometry(int V, int T, int M, int K) {
+ChainGeom chain_geometry(int V, int T, int M, int K, bool bch = false) {
   constexpr int BM = TM * 32, FT = NW;
   ChainGeom g;
   g.ntiles = (T + FT - 1) / FT;
@@ -394,8 +480,8 @@ ChainGeom chain_geometry(int V, int T, int M, int K) {
   g.nmb = (M + BM - 1) / BM;
   g.XP = (FT * V) | 1;
   const size_t a_img = (size_t)3 * 2 * TM * 1024;
-  const size_t xb_bytes = ((size_t)CB * g.XP * 4 + 15) & ~(size_t)15;
-  g.smem_bytes = (size_t)3 * 32 * 32 * 4 + xb_bytes + 2 * a_img;
+  const size_t xb_bytes = ((size_t)CB * g.XP * 4 + (bch ? 32 : 0) + 15) & ~(size_t)15;
+  g.smem_bytes = (bch ? (size_t)3 * 3 * 2 * 2 * 32 * 16 : (size_t)3 * 32 * 32 * 4) + xb_bytes + 2 * a_img;
   const size_t epi_bytes = (size_t)BM * ((FT * V) | 1) * 4 + (size_t)NW * 64 * 2 * 4;
   if (epi_bytes > g.smem_bytes) g.smem_bytes = epi_bytes;
   g.smem_bytes = (g.smem_bytes + 15) & ~(size_t)15;
@@ -413,7 +499,7 @@ struct ChainW2 {
 template <int TM, int VS, int NW>
 int chain_launch(ChainArgs a, const float* w, long sa_m, long sa_i, long sa_c, const ChainW2& g_w2, void* ws,
                  size_t ws_bytes, hipStream_t stream) {
-  const ChainGeom g = chain_geometry<TM, NW>(a.V, a.T, a.M, a.K);
+  const ChainGeom g = chain_geometry<TM, NW>(a.V, a.T, a.M, a.K, VS == 0);
   if (g.smem_bytes > 160 * 1024) return AGCN_ERR_UNSUPPORTED;
   a.ncb2 = a.in2 ? (a.K2 + CB - 1) / CB : 0;
   const int s_total = 3 * g.ncb + a.ncb2;
@@ -447,6 +533,10 @@ int chain_launch(ChainArgs a, const float* w, long sa_m, long sa_i, long sa_c, c
 template <int TM, int NW>
 int chain_dispatch_vs(const ChainArgs& a, const float* w, long sa_m, long sa_i, long sa_c, const ChainW2& w2, void* ws,
                       size_t ws_bytes, hipStream_t stream) {
+  // split-bf16 aggregation unless AGCN_CHAIN_F32=1 (exact-f32 MFMA chain, VS = ceil(V/2) steps) or AGCN_GEMM=bf16
+  // (one product: keep the aggregation exact)
+  static const int f32chain = getenv("AGCN_CHAIN_F32") ? atoi(getenv("AGCN_CHAIN_F32")) : 0;
+  if (!f32chain && a.npl == 3) return chain_launch<TM, 0, NW>(a, w, sa_m, sa_i, sa_c, w2, ws, ws_bytes, stream);
   const int vs = (a.V + 1) / 2;
   if (vs == 13) return chain_launch<TM, 13, NW>(a, w, sa_m, sa_i, sa_c, w2, ws, ws_bytes, stream);
   if (vs == 9) return chain_launch<TM, 9, NW>(a, w, sa_m, sa_i, sa_c, w2, ws, ws_bytes, stream);
@@ -736,6 +826,7 @@ int agcn_gcn_chain(int mode, const float* in, const float* adj, const float* wca
                    int N, int C, int Cout, int T, int V, hipStream_t stream) {
   ChainArgs a = {};
   a.npl = agcn_npl();
+  { static const int dbg = getenv("AGCN_GC_DBG") ? atoi(getenv("AGCN_GC_DBG")) : 0; a.dbg = dbg; }
   // optional fused 1x1 term (backward-data only): out += W2^T . in2 with w2 (K2, M) row-major, e.g. the theta/phi
   // branch  dx += Wab^T dtp  (reference agcn.py:99-100 differentiated)
   a.in2 = (in2 && w2 && K2 > 0) ? in2 : nullptr;

@@ -320,7 +320,11 @@ __global__ void __launch_bounds__((NWC + NWP) * 64, 3) wgrad_pc_kernel(const WcA
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int V = a.V, XP = a.XP;
   const int FTV = FT * V;
-  const int BUF_BYTES = DY_BYTES + CG * XP * 4 + (AGG ? 3 * 32 * 32 * 4 : 0);
+  // VS == 0: the aggregation chain runs on split-bf16 MFMA (12 MFMAs of 32 cycles for K = 32 joints instead of VS
+  // exact-f32 steps of 64 cycles): adjacencies kept as bf16 planes [subset][plane][ks][h][v][8 u] (gcn_chain.hip)
+  constexpr bool BCH = AGG && VS == 0;
+  constexpr int ADJ_BYTES = !AGG ? 0 : (BCH ? 3 * 3 * 2 * 2 * 32 * 16 : 3 * 32 * 32 * 4);
+  const int BUF_BYTES = DY_BYTES + ((CG * XP * 4 + 15) & ~15) + ADJ_BYTES;
   const long Pout = (long)a.T_out * V, Psrc = (long)a.T_src * V;
 
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -431,19 +435,45 @@ __global__ void __launch_bounds__((NWC + NWP) * 64, 3) wgrad_pc_kernel(const WcA
       if (AGG && n != adj_n[p & 1]) {
         // zero-padded adjacencies of this sample, adjp[subset][u][v] (a buffer keeps them while the sample lasts)
         adj_n[p & 1] = n;
-        float* adjp = xs + CG * XP;
         const float* adjn = a.adj + (long)n * 3 * V * V;
-        for (int e = ptid; e < 3 * 32 * 32; e += NTP) {
-          const int sub = e >> 10, u = (e >> 5) & 31, v = e & 31;
-          const bool ok = u < V && v < V;
-          const float tv = adjn[ok ? ((sub * V + u) * V + v) : 0];
-          adjp[e] = ok ? tv : 0.f;
+        if constexpr (!BCH) {
+          float* adjp = reinterpret_cast<float*>(buf + BUF_BYTES - ADJ_BYTES);
+          for (int e = ptid; e < 3 * 32 * 32; e += NTP) {
+            const int sub = e >> 10, u = (e >> 5) & 31, v = e & 31;
+            const bool ok = u < V && v < V;
+            const float tv = adjn[ok ? ((sub * V + u) * V + v) : 0];
+            adjp[e] = ok ? tv : 0.f;
+          }
+        } else {
+          unsigned char* adjq = buf + BUF_BYTES - ADJ_BYTES;
+          for (int e = ptid; e < 3 * 2 * 2 * 32 * 4; e += NTP) {       // one pair (u, u+1) per iteration
+            const int e2 = e & 3, col = (e >> 2) & 31, hh = (e >> 7) & 1, ks = (e >> 8) & 1, sub = e >> 9;
+            float vv[2];
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+              const int u = 16 * ks + 8 * hh + 2 * e2 + q;
+              const bool ok = u < V && col < V;
+              const float tv = adjn[ok ? ((sub * V + u) * V + col) : 0];
+              vv[q] = ok ? tv : 0.f;
+            }
+            unsigned q0, q1, q2;
+            wc_split_pair(vv[0], vv[1], q0, q1, q2);
+            const int o = (((ks * 2 + hh) * 32) + col) * 16 + e2 * 4;
+            *reinterpret_cast<unsigned*>(adjq + (sub * 3 + 0) * 2048 + o) = q0;
+            *reinterpret_cast<unsigned*>(adjq + (sub * 3 + 1) * 2048 + o) = q1;
+            *reinterpret_cast<unsigned*>(adjq + (sub * 3 + 2) * 2048 + o) = q2;
+          }
         }
       }
     };
     if (XP > FTV)                                // the pad element of a row is read (times zero) by the chain
       for (int e = threadIdx.x - NWC * 64; e < 2 * CG; e += NTP)
         reinterpret_cast<float*>(smem + (e / CG) * BUF_BYTES + DY_BYTES)[(e % CG) * XP + FTV] = 0.f;
+    {                                            // the alignment gap behind the last x row is read too (times zero)
+      const int gap = (((CG * XP * 4 + 15) & ~15) - CG * XP * 4) / 4;
+      const int e = threadIdx.x - NWC * 64;
+      if (e < 2 * gap) reinterpret_cast<float*>(smem + (e / max(gap, 1)) * BUF_BYTES + DY_BYTES)[CG * XP + e % max(gap, 1)] = 0.f;
+    }
     if (p_begin < p_end) {
       issue(p_begin);
       commit(p_begin, smem + (p_begin & 1) * BUF_BYTES);
@@ -486,21 +516,48 @@ __global__ void __launch_bounds__((NWC + NWP) * 64, 3) wgrad_pc_kernel(const WcA
         // ---- G^T[v][c] for (frame f, this wave's 32 channels, subset sub) in D layout ----
         f32x16 d;
         if (AGG) {
-          const float* adjp = xs + CG * XP + sub * 1024;
-          // (re-read x for every subset: kept across the subsets, these VS registers push the contraction into spills)
-          const float* xrs = xr;
-          asm volatile("" : "+v"(xrs));
 #pragma unroll
           for (int j = 0; j < 16; ++j) d[j] = 0.f;
-          float ao[VS], xo[VS];
+          // (x is re-read for every subset: kept across the subsets its registers push the contraction into spills)
+          const float* xrs = xr;
+          asm volatile("" : "+v"(xrs));
+          if constexpr (!BCH) {
+            const float* adjp = reinterpret_cast<const float*>(dyi + BUF_BYTES - ADJ_BYTES) + sub * 1024;
+            float ao[BCH ? 1 : VS], xo[BCH ? 1 : VS];
 #pragma unroll
-          for (int s = 0; s < VS; ++s) {
-            ao[s] = adjp[(2 * s + h) * 32 + lr];                 // A operand: A^[u = 2s+h][v = lane]
-            xo[s] = xrs[2 * s + h];          // B operand: x[c = lane][t][u = 2s+h]; u = V (odd V) reads a finite
-                                             // neighbour or the zeroed pad, and A^[u >= V] = 0
+            for (int s = 0; s < VS; ++s) {
+              ao[s] = adjp[(2 * s + h) * 32 + lr];                 // A operand: A^[u = 2s+h][v = lane]
+              xo[s] = xrs[2 * s + h];          // B operand: x[c = lane][t][u = 2s+h]; u = V (odd V) reads a finite
+                                               // neighbour or the zeroed pad, and A^[u >= V] = 0
+            }
+#pragma unroll
+            for (int s = 0; s < VS; ++s) d = mfma32(ao[s], xo[s], d);
+          } else {
+            // G^T = A^_sub^T . x^T: A operand = adjacency planes (row v = lane), B operand = this lane's channel, joints
+            // 16 ks + 8 h + e (beyond V: finite neighbours that meet the zero rows of the adjacency)
+            const unsigned char* aq = dyi + BUF_BYTES - ADJ_BYTES + sub * 3 * 2048 + (h * 32 + lr) * 16;
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+              u32x4 qh, qm, ql;
+#pragma unroll
+              for (int e2 = 0; e2 < 4; ++e2) {
+                unsigned q0, q1, q2;
+                wc_split_pair(xrs[16 * ks + 8 * h + 2 * e2], xrs[16 * ks + 8 * h + 2 * e2 + 1], q0, q1, q2);
+                qh[e2] = q0; qm[e2] = q1; ql[e2] = q2;
+              }
+              const bf16x8 x0 = __builtin_bit_cast(bf16x8, qh), x1 = __builtin_bit_cast(bf16x8, qm),
+                           x2 = __builtin_bit_cast(bf16x8, ql);
+              const bf16x8 a0 = *reinterpret_cast<const bf16x8*>(aq + 0 * 2048 + ks * 1024);
+              const bf16x8 a1 = *reinterpret_cast<const bf16x8*>(aq + 1 * 2048 + ks * 1024);
+              const bf16x8 a2 = *reinterpret_cast<const bf16x8*>(aq + 2 * 2048 + ks * 1024);
+              d = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, x0, d, 0, 0, 0);
+              d = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, x2, d, 0, 0, 0);
+              d = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, x1, d, 0, 0, 0);
+              d = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, x0, d, 0, 0, 0);
+              d = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, x1, d, 0, 0, 0);
+              d = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, x0, d, 0, 0, 0);
+            }
           }
-#pragma unroll
-          for (int s = 0; s < VS; ++s) d = mfma32(ao[s], xo[s], d);
         } else {
 #pragma unroll
           for (int j = 0; j < 16; ++j) {
@@ -675,14 +732,15 @@ size_t wc_slabs(int N, int M, int C, int V, int T_out) {
 
 // ---- producer / consumer variant: geometry, launch, dispatch ----
 template <int AGG, int TM, int NCB, int NRB>
-WcGeom wc_geom_pc(int N, int M, int C, int V, int T_out) {
+WcGeom wc_geom_pc(int N, int M, int C, int V, int T_out, bool bch = false) {
   constexpr int BM = TM * 32 * NRB, NFG = 8 / (NCB * NRB), FT = NFG, CG = NCB * 32;
   WcGeom g;
   g.ntiles = (T_out + FT - 1) / FT;
   g.ncg = (C + CG - 1) / CG;
   g.nmb = (M + BM - 1) / BM;
   g.XP = (FT * V) | 1;
-  g.smem_bytes = 2 * ((size_t)3 * FT * 4 * (BM + 1) * 16 + (size_t)CG * g.XP * 4 + (AGG ? 3 * 32 * 32 * 4 : 0)) + 32;
+  g.smem_bytes = 2 * ((size_t)3 * FT * 4 * (BM + 1) * 16 + (((size_t)CG * g.XP * 4 + 15) & ~(size_t)15) +
+                      (AGG ? (bch ? (size_t)3 * 3 * 2 * 2 * 32 * 16 : (size_t)3 * 32 * 32 * 4) : 0)) + 32;
   g.grid_x = g.nmb * g.ncg;
   const int pairs = N * g.ntiles;
   int want = 256 / g.grid_x;                   // one 12-wave workgroup per CU
@@ -696,7 +754,7 @@ WcGeom wc_geom_pc(int N, int M, int C, int V, int T_out) {
 
 template <int AGG, int TM, int NCB, int NRB, int VS>
 int wc_launch_pc(WcArgs a, void* ws, size_t ws_bytes, int* nslabs_out, hipStream_t stream) {
-  const WcGeom g = wc_geom_pc<AGG, TM, NCB, NRB>(a.N, a.M, a.C, a.V, a.T_out);
+  const WcGeom g = wc_geom_pc<AGG, TM, NCB, NRB>(a.N, a.M, a.C, a.V, a.T_out, AGG && VS == 0);
   if (g.smem_bytes > 160 * 1024) return AGCN_ERR_UNSUPPORTED;
   if ((size_t)g.nslabs * a.wsize * 4 > ws_bytes) return AGCN_ERR_WORKSPACE;
   a.part = (float*)ws;
@@ -716,6 +774,10 @@ int wc_dispatch_pc_vs(const WcArgs& a, void* ws, size_t ws_bytes, int* nslabs, h
   if constexpr (!AGG) {
     return wc_launch_pc<AGG, TM, NCB, NRB, 1>(a, ws, ws_bytes, nslabs, s);
   } else {
+    // (the split-bf16 aggregation measured 3-7 % SLOWER here: the consumer re-splits its x fragment for every subset
+    // and becomes VALU-bound; AGCN_WC_BCH=1 selects it)
+    static const int bch = getenv("AGCN_WC_BCH") ? atoi(getenv("AGCN_WC_BCH")) : 0;
+    if (bch && a.npl == 3) return wc_launch_pc<AGG, TM, NCB, NRB, 0>(a, ws, ws_bytes, nslabs, s);
     if (vs == 13) return wc_launch_pc<AGG, TM, NCB, NRB, 13>(a, ws, ws_bytes, nslabs, s);
     if (vs == 9) return wc_launch_pc<AGG, TM, NCB, NRB, 9>(a, ws, ws_bytes, nslabs, s);
     return wc_launch_pc<AGG, TM, NCB, NRB, 16>(a, ws, ws_bytes, nslabs, s);
