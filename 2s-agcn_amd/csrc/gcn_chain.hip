@@ -21,6 +21,7 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef f32x4 f32x4_u __attribute__((aligned(4)));     // activation rows are only 4-byte aligned
 
 constexpr int CB = 32;                    // channels per stage
 
@@ -634,21 +635,37 @@ __global__ void __launch_bounds__(NW * 64, 2) gcn_dadj_chain_kernel(const DadjAr
 #pragma unroll
     for (int j = 0; j < 16; ++j) acc[tm][j] = 0.f;
 
+  // dy staging: lane task = (8-channel group og = ks*2 + h, 4 consecutive positions): eight 16-byte loads (one per
+  // channel) instead of 32 scalar ones -- the per-CU address path, not HBM, bounded the scalar version.  Positions
+  // beyond the tile's valid frames are never used (their waves skip), so nothing is masked; only the last positions of
+  // the whole tensor take the clamped scalar path.
   u32x4 ra[EA];
-  float rb[BI][8];
+  f32x4 rb[8];
   const u32x4* wp4 = reinterpret_cast<const u32x4*>(a.wp) + (long)mbk * S * A16;
+  const int npiece = (PT + 3) >> 2, ntask = 4 * npiece;
+  const float* dy_end = a.dy + (long)a.N * a.Cout * P;
   auto issue = [&](int s) __attribute__((always_inline)) {
     const u32x4* src = wp4 + (long)s * A16;
 #pragma unroll
     for (int u = 0; u < EA; ++u) ra[u] = src[min(tid + u * NT, A16 - 1)];
-#pragma unroll
-    for (int k = 0; k < BI; ++k) {
-      const int item = tid + k * NT;
-      const int og = item / PT, pos = item - og * PT;
+    int tk = tid;
+    asm volatile("" : "+v"(tk));                       // (keeps the task indices out of loop-invariant registers)
+    if (tk < ntask) {
+      const int og = tk / npiece, pos = (tk - og * npiece) * 4;
       const int o0 = s * KC + og * 8;
-      const float* src2 = a.dy + ((long)n * a.Cout) * P + (long)t0 * V + ((pos < plen) ? pos : 0);
+      const float* src2 = a.dy + ((long)n * a.Cout + min(o0, a.Cout - 8)) * P + (long)t0 * V + pos;
+      if (src2 + 7 * P + 4 <= dy_end) {
 #pragma unroll
-      for (int e = 0; e < 8; ++e) rb[k][e] = src2[(long)min(o0 + e, a.Cout - 1) * P];
+        for (int e = 0; e < 8; ++e) rb[e] = *reinterpret_cast<const f32x4_u*>(src2 + (long)e * P);
+      } else {
+#pragma unroll
+        for (int e = 0; e < 8; ++e)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const float* pq = src2 + (long)e * P + q;
+            rb[e][q] = (pq < dy_end) ? *pq : 0.f;
+          }
+      }
     }
   };
   auto commit = [&](int s) __attribute__((always_inline)) {
@@ -657,24 +674,24 @@ __global__ void __launch_bounds__(NW * 64, 2) gcn_dadj_chain_kernel(const DadjAr
     for (int u = 0; u < EA; ++u)
       if (tid + u * NT < A16) dst[tid + u * NT] = ra[u];
     unsigned char* bd = bbuf + (s & 1) * B_IMG;
+    int tk = tid;
+    asm volatile("" : "+v"(tk));
+    if (tk < ntask) {
+      const int og = tk / npiece, pos = (tk - og * npiece) * 4;   // og = ks*2 + h
 #pragma unroll
-    for (int k = 0; k < BI; ++k) {
-      const int item = tid + k * NT;
-      const int og = item / PT, pos = item - og * PT;
-      const int o0 = s * KC + og * 8;
-      u32x4 ph, pm, pl;
+      for (int q = 0; q < 4; ++q) {
+        u32x4 ph, pm, pl;
 #pragma unroll
-      for (int e2 = 0; e2 < 4; ++e2) {
-        const float v0 = (pos < plen && o0 + 2 * e2 < a.Cout) ? rb[k][2 * e2] : 0.f;
-        const float v1 = (pos < plen && o0 + 2 * e2 + 1 < a.Cout) ? rb[k][2 * e2 + 1] : 0.f;
-        unsigned q0, q1, q2;
-        split_pair(v0, v1, q0, q1, q2);
-        ph[e2] = q0; pm[e2] = q1; pl[e2] = q2;
-      }
-      if (og < 4) {                                    // og = ks*2 + h
-        *reinterpret_cast<u32x4*>(bd + ((0 * 4 + og) * PT + pos) * 16) = ph;
-        *reinterpret_cast<u32x4*>(bd + ((1 * 4 + og) * PT + pos) * 16) = pm;
-        *reinterpret_cast<u32x4*>(bd + ((2 * 4 + og) * PT + pos) * 16) = pl;
+        for (int e2 = 0; e2 < 4; ++e2) {
+          unsigned q0, q1, q2;
+          split_pair(rb[2 * e2][q], rb[2 * e2 + 1][q], q0, q1, q2);
+          ph[e2] = q0; pm[e2] = q1; pl[e2] = q2;
+        }
+        if (pos + q < PT) {
+          *reinterpret_cast<u32x4*>(bd + ((0 * 4 + og) * PT + pos + q) * 16) = ph;
+          *reinterpret_cast<u32x4*>(bd + ((1 * 4 + og) * PT + pos + q) * 16) = pm;
+          *reinterpret_cast<u32x4*>(bd + ((2 * 4 + og) * PT + pos + q) * 16) = pl;
+        }
       }
     }
   };
