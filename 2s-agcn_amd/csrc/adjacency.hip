@@ -209,33 +209,42 @@ scores_bwd_kernel(const float* __restrict__ tp, const float* __restrict__ dS, fl
   const int nrt = (nrows + 31) >> 5;
   for (int c0 = 0; c0 < Ci; c0 += SC_CK) {
     __syncthreads();
-    // the whole chunk (4 rows x 2 tensors x up to 4 column blocks per lane) is fetched before anything is written
-    // to LDS: 32 loads in flight per lane instead of 8 (the kernel is latency-bound, not bandwidth-bound)
+    // 16-byte loads, lane <-> 4 consecutive positions of a row (tt*V <= 256): 8 vector loads per lane and chunk instead
+    // of 32 scalar ones -- the scalar version ran at the pace of the CU's address path, not of HBM.  What a lane reads
+    // beyond the tile (next frames of the row) is masked below; only the last rows of the tensor take the clamped path.
     {
-      float v1[4][SC_CK / 4], v2[4][SC_CK / 4];
+      typedef f32x4 f32x4_u __attribute__((aligned(4)));
+      const float* tp_end = tp + (long)N * 6 * Ci * P;
+      f32x4 v1[SC_CK / 4], v2[SC_CK / 4];
+      const int q0 = 4 * lane;
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        const int q = lane + 64 * u;
+      for (int j = 0; j < SC_CK / 4; ++j) {
+        const int cl = wave + 4 * j;
+        const bool okr = (c0 + cl) < Ci;
+        const float* s1 = tp + (row0 + c0 + (okr ? cl : 0)) * P + (long)t0 * V + q0;
+        const float* s2 = s1 + (long)Ci * P;
+        if (s2 + 4 <= tp_end) {
+          v1[j] = *reinterpret_cast<const f32x4_u*>(s1);
+          v2[j] = *reinterpret_cast<const f32x4_u*>(s2);
+        } else {
 #pragma unroll
-        for (int j = 0; j < SC_CK / 4; ++j) {
-          const int cl = wave + 4 * j;
-          const bool okr = (c0 + cl) < Ci;
-          const bool ok = okr && q < nvalid;
-          const float* s1 = tp + (row0 + c0 + (okr ? cl : 0)) * P + (long)t0 * V;
-          v1[u][j] = s1[ok ? q : 0];
-          v2[u][j] = s1[(long)Ci * P + (ok ? q : 0)];
+          for (int e = 0; e < 4; ++e) {
+            v1[j][e] = (s1 + e < tp_end) ? s1[e] : 0.f;
+            v2[j][e] = (s2 + e < tp_end) ? s2[e] : 0.f;
+          }
         }
       }
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        const int q = lane + 64 * u;
+      for (int j = 0; j < SC_CK / 4; ++j) {
+        const int cl = wave + 4 * j;
+        const bool okr = (c0 + cl) < Ci;
 #pragma unroll
-        for (int j = 0; j < SC_CK / 4; ++j) {
-          const int cl = wave + 4 * j;
-          const bool ok = (c0 + cl) < Ci && q < nvalid;
+        for (int e = 0; e < 4; ++e) {
+          const int q = q0 + e;
           if (q < ttv) {
-            Th[cl * ttv + q] = ok ? v1[u][j] : 0.f;
-            Ph[cl * ttv + q] = ok ? v2[u][j] : 0.f;
+            const bool ok = okr && q < nvalid;
+            Th[cl * ttv + q] = ok ? v1[j][e] : 0.f;
+            Ph[cl * ttv + q] = ok ? v2[j][e] : 0.f;
           }
         }
       }
@@ -289,13 +298,22 @@ scores_bwd_kernel(const float* __restrict__ tp, const float* __restrict__ dS, fl
           const bool okr = (c0 + cl) < Ci;
           float* drow = dtp + (row0 + (long)which * Ci + c0 + (okr ? cl : 0)) * P + (long)t0 * V;
           float sum = 0.f;
+          {                                    // lane <-> 4 consecutive positions: one 16-byte store when all are valid
+            typedef f32x4 f32x4_u __attribute__((aligned(4)));
+            const int q = 4 * lane;
+            if (okr && q + 3 < nvalid) {
+              f32x4 val;
 #pragma unroll
-          for (int u = 0; u < 4; ++u) {
-            const int q = lane + 64 * u;
-            if (okr && q < nvalid) {
-              const float val = buf[cl * ttv + q];
-              drow[q] = val;
-              sum += val;
+              for (int e = 0; e < 4; ++e) { val[e] = buf[cl * ttv + q + e]; sum += val[e]; }
+              *reinterpret_cast<f32x4_u*>(drow + q) = val;
+            } else if (okr) {
+#pragma unroll
+              for (int e = 0; e < 4; ++e)
+                if (q + e < nvalid) {
+                  const float val = buf[cl * ttv + q + e];
+                  drow[q + e] = val;
+                  sum += val;
+                }
             }
           }
           sum = half_sum(sum);

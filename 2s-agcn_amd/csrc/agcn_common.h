@@ -58,14 +58,16 @@ int agcn_adj_finalize(const float* spart, const float* A, const float* PA, const
 size_t agcn_bf16_conv_workspace(int Cin, int Cout, int T, int V, int stride);
 bool agcn_bf16_conv_wide(int taps, int M);
 int agcn_bf16_conv9_fwd(const float* x, const float* w, const float* bias, float* y, float* stats_part, void* ws,
-                        size_t ws_bytes, int N, int Cin, int Cout, int T, int V, int stride, int npl, hipStream_t s);
+                        size_t ws_bytes, int N, int Cin, int Cout, int T, int V, int stride, int npl, hipStream_t s,
+                        const float* add = nullptr, int relu = 0);
 int agcn_bf16_conv9_bwd_data(const float* dy, const float* w, float* dx, int accumulate, const float* add1,
                              const float* mask1, const float* add2, const float* mask2, void* ws, size_t ws_bytes,
                              int N, int Cin, int Cout, int T, int V, int stride, int npl, hipStream_t s);
 
 size_t agcn_bf16_conv1_workspace(int Cin, int Cout, int T, int V, int stride);
 int agcn_bf16_conv1_fwd(const float* x, const float* w, const float* bias, float* y, float* stats_part, void* ws,
-                        size_t ws_bytes, int N, int Cin, int Cout, int T, int V, int stride, int npl, hipStream_t s);
+                        size_t ws_bytes, int N, int Cin, int Cout, int T, int V, int stride, int npl, hipStream_t s,
+                        const float* add = nullptr, int relu = 0);
 int agcn_bf16_conv1_bwd_data(const float* dy, const float* w, float* dx, int accumulate, const float* add1,
                              const float* mask1, const float* add2, const float* mask2, void* ws, size_t ws_bytes,
                              int N, int Cin, int Cout, int T, int V, int npl, hipStream_t s);
@@ -77,7 +79,7 @@ size_t agcn_gcn_chain_workspace(int M, int K, int K2, int T, int V);
 int agcn_gcn_chain(int mode, const float* in, const float* adj, const float* wcat, const float* bias, float* out,
                    float* stats_part, int accumulate, const float* add1, const float* mask1, const float* add2,
                    const float* mask2, int mask_bits, const float* in2, const float* w2, int K2, void* ws, size_t ws_bytes,
-                   int N, int C, int Cout, int T, int V, hipStream_t stream);
+                   int N, int C, int Cout, int T, int V, hipStream_t stream, int relu = 0, int w2_rows_are_outputs = 0);
 
 bool agcn_gcn_dadj_chain_supported(int C, int V);
 int agcn_gcn_dadj_chain_slots(int C, int T);

@@ -718,6 +718,39 @@ int agcn_gcn_aggregate_project_fwd(const float* x, const float* adj, const float
   return DISPATCH_BM(1, 1, CKA, CKA, 4, p, (hipStream_t)stream);
 }
 
+// ---- BN-folded inference (eval mode): the BatchNorm that follows a contraction is folded into its weights and bias
+// by the caller; the residual add and the ReLU ride in the store epilogue, so a unit is adjacency + two kernels ----
+// y = act( bias + sum_i W_i (x . adj_i) [+ res] [+ W2 . x2] ),  W2 (Cout, K2) row-major (a folded 1x1 `down` conv on x2)
+// Only on the chained split-bf16 path (C >= 32): AGCN_ERR_UNSUPPORTED otherwise (the caller runs the unfused passes).
+int agcn_gcn_unit_infer(const float* x, const float* adj, const float* wcat, const float* bias, const float* res,
+                        const float* x2, const float* w2, int K2, int relu, float* y, void* workspace,
+                        size_t workspace_bytes, int N, int C, int Cout, int T, int V, void* stream) {
+  if (!x || !adj || !wcat || !y || !workspace || N <= 0 || C <= 0 || Cout <= 0 || T <= 0 || V <= 0 || V > 32)
+    return AGCN_ERR_ARG;
+  if ((x2 == nullptr) != (w2 == nullptr) || (x2 && K2 <= 0)) return AGCN_ERR_ARG;
+  if (!(agcn_chained() && C >= 32 && agcn_gcn_chain_supported(Cout, C, V))) return AGCN_ERR_UNSUPPORTED;
+  if (x2 && K2 % 32 != 0) return AGCN_ERR_UNSUPPORTED;
+  if (agcn_gcn_chain_workspace(Cout, C, x2 ? K2 : 0, T, V) > workspace_bytes) return AGCN_ERR_WORKSPACE;
+  return agcn_gcn_chain(0, x, adj, wcat, bias, y, nullptr, 0, res, nullptr, nullptr, nullptr, 0, x2, w2, x2 ? K2 : 0,
+                        workspace, workspace_bytes, N, C, Cout, T, V, (hipStream_t)stream, relu, 1);
+}
+
+size_t agcn_gcn_unit_infer_workspace(int C, int Cout, int K2, int T, int V) {
+  return agcn_gcn_chain_workspace(Cout, C, K2, T, V) + 256;
+}
+
+// y = act( bias + conv9x1(x; w, stride) [+ res] ),  res (N, Cout, T_out, V).  Split-bf16 modes only.
+int agcn_conv9_infer(const float* x, const float* w, const float* bias, const float* res, int relu, float* y,
+                     void* workspace, size_t workspace_bytes, int N, int Cin, int Cout, int T, int V, int stride,
+                     void* stream) {
+  if (!x || !w || !y || !workspace || N <= 0 || Cin <= 0 || Cout <= 0 || T <= 0 || V <= 0 || V > 32)
+    return AGCN_ERR_ARG;
+  if (stride != 1 && stride != 2) return AGCN_ERR_UNSUPPORTED;
+  if (agcn_gemm_precision() == 0) return AGCN_ERR_UNSUPPORTED;
+  return agcn_bf16_conv9_fwd(x, w, bias, y, nullptr, workspace, workspace_bytes, N, Cin, Cout, T, V, stride,
+                             agcn_gemm_precision(), (hipStream_t)stream, res, relu);
+}
+
 // dx[n][c][t,u] (+)= sum_i sum_o wcat[o][i*C+c] * sum_v dy[n][o][t,v] adj[n][i][u][v]   (+ masked addends)
 int agcn_gcn_aggregate_project_bwd_data(const float* dy, const float* adj, const float* wcat, float* dx,
                                         int accumulate, const float* add1, const float* mask1, const float* add2,

@@ -44,6 +44,7 @@ struct BfArgs {
   int off_b;                   // byte offset of the B image in LDS
   int off_bias;                // byte offset of the bias row in LDS
   int dbg;                     // profiling switches (AGCN_CB_DBG): 1 = no MFMA loop, 2 = stage chunk 0 only, 4 = no epilogue
+  int relu;                    // epilogue: out = max(., 0) (BN-folded inference)
 };
 
 struct BfPackArgs {
@@ -288,7 +289,7 @@ __global__ void __launch_bounds__(NT, (TAPS == 1 && TM == 2 && TN == 1) ? 4 : 2)
   }
   EpiPtrs ep;
   ep.out = a.out; ep.add1 = a.add1; ep.mask1 = a.mask1; ep.add2 = a.add2; ep.mask2 = a.mask2; ep.stats = a.stats;
-  ep.accumulate = a.accumulate;
+  ep.accumulate = a.accumulate; ep.relu = a.relu;
   const long Pfull = (long)a.T_full * V;
   const long rows0 = (long)n * a.M * Pfull + ((long)t0 * a.out_fs + a.out_fo) * V;
   epilogue_rows<BM, NW, 4 * TN>(ep, tile, TP, bias_s, red, a.M, m0, rows0, Pfull, nvalid, poff, (long)n * a.ntiles + tile_id);
@@ -530,7 +531,7 @@ __global__ void __launch_bounds__((8 + NWP) * 64, 3) conv_pc_kernel(const BfArgs
   }
   EpiPtrs ep;
   ep.out = a.out; ep.add1 = a.add1; ep.mask1 = a.mask1; ep.add2 = a.add2; ep.mask2 = a.mask2; ep.stats = a.stats;
-  ep.accumulate = a.accumulate;
+  ep.accumulate = a.accumulate; ep.relu = a.relu;
   const long Pfull = (long)a.T_full * V;
   const long rows0 = (long)n * a.M * Pfull + ((long)t0 * a.out_fs + a.out_fo) * V;
   epilogue_rows<BM, NWC, 4>(ep, tile, TP, bias_s, red, a.M, m0, rows0, Pfull, nvalid, poff, (long)n * a.ntiles + tile_id);
@@ -748,10 +749,10 @@ size_t agcn_bf16_conv_workspace(int Cin, int Cout, int T, int V, int stride) {
 
 int agcn_bf16_conv9_fwd(const float* x, const float* w, const float* bias, float* y, float* stats_part, void* ws,
                         size_t ws_bytes, int N, int Cin, int Cout, int T, int V, int stride, int npl,
-                        hipStream_t s) {
+                        hipStream_t s, const float* add, int relu) {
   BfProblem p = {};
   BfArgs& a = p.a;
-  a.in = x; a.bias = bias; a.out = y; a.stats = stats_part;
+  a.in = x; a.bias = bias; a.out = y; a.stats = stats_part; a.add1 = add; a.relu = relu;
   a.N = N; a.M = Cout; a.Kinner = Cin; a.in_rows = Cin; a.V = V;
   a.T_src = T; a.T_out = (T + 8 - 9) / stride + 1; a.T_full = a.T_out;
   a.src_stride = stride; a.f_off = -4; a.out_fs = 1; a.out_fo = 0;
@@ -790,10 +791,10 @@ int agcn_bf16_conv9_bwd_data(const float* dy, const float* w, float* dx, int acc
 // 1x1 convolutions (conv_a/conv_b/down/residual; reference agcn.py:66-75,122-125) on the same kernel, TAPS = 1
 int agcn_bf16_conv1_fwd(const float* x, const float* w, const float* bias, float* y, float* stats_part, void* ws,
                         size_t ws_bytes, int N, int Cin, int Cout, int T, int V, int stride, int npl,
-                        hipStream_t s) {
+                        hipStream_t s, const float* add, int relu) {
   BfProblem p = {};
   BfArgs& a = p.a;
-  a.in = x; a.bias = bias; a.out = y; a.stats = stats_part;
+  a.in = x; a.bias = bias; a.out = y; a.stats = stats_part; a.add1 = add; a.relu = relu;
   a.N = N; a.M = Cout; a.Kinner = Cin; a.in_rows = Cin; a.V = V;
   a.T_src = T; a.T_out = (T - 1) / stride + 1; a.T_full = a.T_out;
   a.src_stride = stride; a.f_off = 0; a.out_fs = 1; a.out_fo = 0;

@@ -15,6 +15,7 @@ struct EpiPtrs {
   const float* mask2;
   float* stats;          // [slot][2][M] or null
   int accumulate;
+  int relu;              // out = max(., 0) (BN-folded inference)
 };
 
 // tile  : [BM][TP] (TP odd) valid for columns q < nvalid; bias_s: [BM] in LDS; red: [NT*2] floats of LDS scratch
@@ -96,6 +97,7 @@ __device__ __forceinline__ void epilogue_rows(const EpiPtrs& e, const float* til
         if (e.accumulate) v += ex[k & 1][0][g][u];
         if (e.add1) v += (!e.mask1 || ex[k & 1][2][g][u] > 0.f) ? ex[k & 1][1][g][u] : 0.f;
         if (e.add2) v += (!e.mask2 || ex[k & 1][4][g][u] > 0.f) ? ex[k & 1][3][g][u] : 0.f;
+        if (e.relu) v = fmaxf(v, 0.f);
         if (q < nvalid) e.out[base + poff[u]] = v;
       }
     }

@@ -47,6 +47,7 @@ struct ChainArgs {
   int off_bias;                // byte offset of the bias row in LDS
   int npl;                     // 3: six split products (bf16x6) ; 1: hi*hi only (bf16)
   int dbg;                     // profiling switches (AGCN_GC_DBG): 1 = no matrix work, 2 = no staging after the prologue
+  int relu;                    // epilogue: out = max(., 0) (BN-folded inference)
 };
 
 struct ChainPackArgs {
@@ -461,6 +462,7 @@ __global__ void __launch_bounds__(NW * 64, 2) gcn_chain_kernel(const ChainArgs a
         const long midx = base + ((q < xlen) ? q : 0);
         if (a.add1) v += (!a.mask1 || mask_pass(ex[k & 1][2][g][u], midx, a.mask_bits)) ? ex[k & 1][1][g][u] : 0.f;
         if (a.add2) v += (!a.mask2 || mask_pass(ex[k & 1][4][g][u], midx, a.mask_bits)) ? ex[k & 1][3][g][u] : 0.f;
+        if (a.relu) v = fmaxf(v, 0.f);
         if (q < xlen) a.out[base + q] = v;
       }
     }
@@ -840,8 +842,9 @@ size_t agcn_gcn_chain_workspace(int M, int K, int K2, int T, int V) {
 int agcn_gcn_chain(int mode, const float* in, const float* adj, const float* wcat, const float* bias, float* out,
                    float* stats_part, int accumulate, const float* add1, const float* mask1, const float* add2,
                    const float* mask2, int mask_bits, const float* in2, const float* w2, int K2, void* ws, size_t ws_bytes,
-                   int N, int C, int Cout, int T, int V, hipStream_t stream) {
+                   int N, int C, int Cout, int T, int V, hipStream_t stream, int relu, int w2_rows_are_outputs) {
   ChainArgs a = {};
+  a.relu = relu;
   a.npl = agcn_npl();
   { static const int dbg = getenv("AGCN_GC_DBG") ? atoi(getenv("AGCN_GC_DBG")) : 0; a.dbg = dbg; }
   // optional fused 1x1 term (backward-data only): out += W2^T . in2 with w2 (K2, M) row-major, e.g. the theta/phi
@@ -856,6 +859,7 @@ int agcn_gcn_chain(int mode, const float* in, const float* adj, const float* wca
   if (mode == 0) { a.M = Cout; a.K = C; a.adj_t = 0; sa_m = 3L * C; sa_i = C; sa_c = 1; }
   else           { a.M = C; a.K = Cout; a.adj_t = 1; sa_m = 1; sa_i = C; sa_c = 3L * C; }
   cw2.sa_c = a.M;        // W2[m][k] = w2[k*M + m]
+  if (w2_rows_are_outputs) { cw2.sa_m = a.K2; cw2.sa_c = 1; }   // w2 (M, K2) row-major (forward: a folded 1x1 conv)
   if (chain_waves() == 8 && chain_tm(a.M) != 1) {
     if (chain_tm(a.M) == 4) return chain_dispatch_vs<4, 8>(a, wcat, sa_m, sa_i, sa_c, cw2, ws, ws_bytes, stream);
     return chain_dispatch_vs<2, 8>(a, wcat, sa_m, sa_i, sa_c, cw2, ws, ws_bytes, stream);

@@ -174,6 +174,15 @@ class TCN_GCN_unit(nn.Module):
             rargs = (r.conv.weight, r.conv.bias) + _bn_args(r.bn)
         else:
             rargs = (None,) * 6
+        if not self.training and not torch.is_grad_enabled() and ops.infer_fold_enabled():
+            # inference: BatchNorms folded into the contractions, residual + ReLU in their epilogues
+            ga = self.gcn1.packed_args()
+            down = None if ga[10] is None else tuple(ga[10:16])
+            y = ops.unit_infer(x, *ga[:6], tuple(ga[6:10]), down, t.conv.weight, t.conv.bias, _bn_args(t.bn),
+                               self.res_mode, rargs if self.res_mode == 2 else None, self.stride,
+                               cache=self.__dict__.setdefault('_infer_cache', {}))
+            if y is not None:
+                return y
         y = ops.TCNGCNUnitFunction.apply(x, *self.gcn1.packed_args(), t.conv.weight, t.conv.bias, *_bn_args(t.bn),
                                          self.res_mode, *rargs, self.stride, self.training, ops.sync_of(t.bn))
         self.gcn1.tick()

@@ -6,6 +6,8 @@ extension never allocates or keeps device memory.  Everything here launches on t
 
 Maths: SURVEY.md Appendix A (checked against the reference ``agcn.py:92-109`` by the oracle tests).
 """
+import os
+
 import torch
 
 from . import lib as _lib
@@ -625,6 +627,114 @@ def tcn_backward(c, dout):
     if drpre is not None:
         dwres = conv_bwd_weight(drpre, c.t_resx, wres.shape, c.t_stride)
     return dg, dw, dg1, db1, drpre, dwres, dg2, db2
+
+
+# ---- BN-folded inference (eval mode under no_grad): adjacency + two kernels per TCN_GCN_unit ----------------------
+ERR_UNSUPPORTED = -3
+
+
+def infer_fold_enabled():
+    """AGCN_INFER_FOLD=0 keeps the eval forward on the unfused passes (A/B and debugging)."""
+    return os.environ.get('AGCN_INFER_FOLD', '1') != '0'
+
+
+def _fold(bn):
+    """(scale, shift) of an eval-mode BatchNorm: y = scale * x + shift  (reference nn.BatchNorm2d in eval mode)."""
+    w, b, rm, rv = bn
+    s = w / torch.sqrt(rv + BN_EPS)
+    return s, b - rm * s
+
+
+def gcn_unit_infer(x, adj, wcat, bias, res=None, x2=None, w2=None, relu=True):
+    """y = act(bias + sum_i W_i (x . adj_i) [+ res] [+ W2 . x2]); None when only the exact-f32 kernels apply."""
+    N, C, T, V = x.shape
+    Cout = wcat.shape[0]
+    K2 = 0 if x2 is None else x2.shape[1]
+    nbytes = _L().agcn_gcn_unit_infer_workspace(C, Cout, K2, T, V)
+    ws = _ws(nbytes, x)
+    y = _empty((N, Cout, T, V), x)
+    rc = _L().agcn_gcn_unit_infer(_lib.ptr(x), _lib.ptr(adj), _lib.ptr(wcat), _lib.ptr(bias), _lib.ptr(res),
+                                  _lib.ptr(x2), _lib.ptr(w2), K2, 1 if relu else 0, _lib.ptr(y), ws.data_ptr(), nbytes,
+                                  N, C, Cout, T, V, _lib.stream())
+    if rc == ERR_UNSUPPORTED:
+        return None
+    _lib.check(rc, "agcn_gcn_unit_infer")
+    return y
+
+
+def conv9_infer(x, w, b, res=None, relu=True, stride=1):
+    """y = act(b + conv9x1(x; w, stride) [+ res]); None when only the exact-f32 kernels apply."""
+    N, Cin, T, V = x.shape
+    Cout = w.shape[0]
+    To = conv_out_frames(T, 9, stride)
+    ws, nbytes = _conv_ws(Cin, Cout, T, V, 9, stride, x)
+    y = _empty((N, Cout, To, V), x)
+    rc = _L().agcn_conv9_infer(_lib.ptr(x), _lib.ptr(w), _lib.ptr(b), _lib.ptr(res), 1 if relu else 0, _lib.ptr(y),
+                               ws.data_ptr(), nbytes, N, Cin, Cout, T, V, stride, _lib.stream())
+    if rc == ERR_UNSUPPORTED:
+        return None
+    _lib.check(rc, "agcn_conv9_infer")
+    return y
+
+
+def unit_infer(x, A, PA, wab, bab, wd, bd, gbn, down, tw, tb, tbn, res_mode, res, stride, alpha=None, adaptive=True,
+               cache=None):
+    """Eval-mode TCN_GCN_unit (reference agcn.py:92-109, 48-50, 127-129) with every BatchNorm folded into the contraction
+    in front of it: adjacency, one aggregate+project kernel (conv `down` as extra plain stages, residual add and ReLU
+    in its epilogue), [the 1x1 stride residual conv], one temporal-conv kernel (residual add + ReLU in its epilogue).
+    gbn / tbn = (weight, bias, running_mean, running_var); down / res = None | (w, b, bn_w, bn_b, bn_rm, bn_rv).
+    Returns None where the fused kernels do not apply (3-channel first layer, AGCN_GEMM=f32): the caller then runs the
+    unfused eval passes.  ``cache`` (a dict owned by the module) keeps the folded weights between calls."""
+    x = x.contiguous()
+    N, C, T, V = x.shape
+    Cout = wd.shape[0]
+    if C < 32:
+        return None
+    srcs = [wd, bd, *gbn, tw, tb, *tbn] + (list(down) if down is not None else []) + \
+           (list(res) if isinstance(res, tuple) else [])
+    key = tuple((t.data_ptr(), t._version) for t in srcs)
+    f = cache.get('folded') if cache is not None else None
+    if f is None or f[0] != key:
+        s1, sh1 = _fold(gbn)
+        wdf = (wd * s1[:, None]).contiguous()
+        bias = bd * s1 + sh1
+        w2 = None
+        if down is not None:
+            s2, sh2 = _fold(down[2:])
+            w2 = (down[0].reshape(Cout, C) * s2[:, None]).contiguous()
+            bias = bias + down[1] * s2 + sh2
+        s3, sh3 = _fold(tbn)
+        twf = (tw * s3[:, None, None, None]).contiguous()
+        tbf = tb * s3 + sh3
+        rwf = rbf = None
+        if isinstance(res, tuple):
+            s4, sh4 = _fold(res[2:])
+            rwf = (res[0] * s4[:, None, None, None]).contiguous()
+            rbf = res[1] * s4 + sh4
+        f = (key, wdf, bias.contiguous(), w2, twf, tbf.contiguous(), rwf, rbf)
+        if cache is not None:
+            cache['folded'] = f
+    _, wdf, bias, w2, twf, tbf, rwf, rbf = f
+    if adaptive and adjacency_fused_supported(C, wab.shape[0] // 6, T, V):
+        _, adj = adjacency_fused_fwd(x, wab, bab, A, PA, alpha)
+    elif adaptive:
+        tp, _ = conv_fwd(x, wab, bab)
+        _, adj = adjacency_fwd(tp, A, PA, alpha)
+    else:
+        adj = A.unsqueeze(0).expand(N, 3, V, V).contiguous()
+    if down is None:
+        g = gcn_unit_infer(x, adj, wdf, bias, res=x)
+    else:
+        g = gcn_unit_infer(x, adj, wdf, bias, x2=x, w2=w2)
+    if g is None:
+        return None
+    if res_mode == 0:
+        r = None
+    elif res_mode == 1:
+        r = x
+    else:
+        r, _ = conv_fwd(x, rwf, rbf, stride)
+    return conv9_infer(g, twf, tbf, r, relu=True, stride=stride)
 
 
 def _need_train(training):

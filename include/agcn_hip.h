@@ -79,6 +79,24 @@ int agcn_gcn_stats_tiles(int C, int Cout, int T, int V);    /* stats_part slots 
 int agcn_gcn_aggregate_project_fwd(const float* x, const float* adj, const float* wcat, const float* bias, float* y,
                                    float* stats_part, void* workspace, size_t workspace_bytes, int N, int C, int Cout,
                                    int T, int V, void* stream);
+/* ---- BN-folded inference (eval mode) ---------------------------------------------------------------------------------
+ * replaces, for model.eval() under no_grad, the whole of unit_gcn.forward after the adjacency (agcn.py:103-109) and of
+ * unit_tcn.forward + the TCN_GCN_unit tail (agcn.py:48-50, 127-129): the caller folds every BatchNorm into the weights
+ * and bias of the contraction in front of it (w' = w * gamma/sqrt(var+eps), b' = (b - mean) * gamma/sqrt(var+eps) + beta),
+ * the residual add and the ReLU ride in the store epilogue.
+ *   agcn_gcn_unit_infer: y = act( bias + sum_i W_i (x . adj_i) [+ res] [+ W2 . x2] ); res (N,Cout,T,V) or NULL (the
+ *     identity `down`); x2 (N,K2,T,V) with w2 (Cout,K2) row-major or both NULL (the folded conv `down`, K2 % 32 == 0)
+ *   agcn_conv9_infer:    y = act( bias + conv9x1(x; w (Cout,Cin,9,1), stride) [+ res] ); res (N,Cout,T_out,V) or NULL
+ * Both return AGCN_ERR_UNSUPPORTED where only the exact-f32 kernels apply (C < 32, AGCN_GEMM=f32): run the unfused
+ * passes then.  Workspace of agcn_conv9_infer: agcn_conv_workspace. */
+size_t agcn_gcn_unit_infer_workspace(int C, int Cout, int K2, int T, int V);
+int agcn_gcn_unit_infer(const float* x, const float* adj, const float* wcat, const float* bias, const float* res,
+                        const float* x2, const float* w2, int K2, int relu, float* y, void* workspace,
+                        size_t workspace_bytes, int N, int C, int Cout, int T, int V, void* stream);
+int agcn_conv9_infer(const float* x, const float* w, const float* bias, const float* res, int relu, float* y,
+                     void* workspace, size_t workspace_bytes, int N, int Cin, int Cout, int T, int V, int stride,
+                     void* stream);
+
 /* mask_bits = 1: mask1/mask2 are sign bit masks of agcn_bn_act_fwd (cast to const float*), 0: fp32 tensors (> 0 passes) */
 int agcn_gcn_aggregate_project_bwd_data(const float* dy, const float* adj, const float* wcat, float* dx,
                                         int accumulate, const float* add1, const float* mask1, const float* add2,

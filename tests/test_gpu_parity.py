@@ -378,3 +378,40 @@ def test_cpu_input_raises():
     unit = TCN_GCN_unit(64, 64, gu.graph_A(25).numpy())
     with pytest.raises(RuntimeError):
         unit(torch.zeros(1, 64, 8, 25))
+
+
+@pytest.mark.gpu
+def test_inference_fold_matches_unfused_eval_and_takes_the_fused_path(monkeypatch):
+    """Eval under no_grad runs the BN-folded chain (adjacency + two kernels per unit).  It must (a) agree with the
+    unfused eval passes of the same weights within the fp32 tolerance, on non-trivial running statistics and with every
+    residual flavour (l1 none / fallback, l2 identity, l5 and l8 strided conv + conv `down`), and (b) actually be taken:
+    the last launch of a 64-channel unit is the temporal-conv kernel with the ReLU epilogue, not a BatchNorm pass."""
+    import agcn_amd
+    from agcn_amd import lib, ops
+    from agcn_amd.model import agcn as magcn
+    dev = torch.device('cuda:0')
+    torch.manual_seed(11)
+    model = magcn.Model(num_class=60, num_point=25, num_person=2, graph='graph.ntu_rgb_d.Graph',
+                        graph_args={'labeling_mode': 'spatial'}).to(dev)
+    g = torch.Generator().manual_seed(5)
+    for m in model.modules():
+        if isinstance(m, (torch.nn.BatchNorm1d, torch.nn.BatchNorm2d)):
+            with torch.no_grad():
+                m.running_mean.copy_((0.2 * torch.randn(m.running_mean.shape, generator=g)).to(dev))
+                m.running_var.copy_((0.5 + torch.rand(m.running_var.shape, generator=g)).to(dev))
+                m.weight.copy_((0.5 + torch.rand(m.weight.shape, generator=g)).to(dev))
+                m.bias.copy_((0.1 * torch.randn(m.bias.shape, generator=g)).to(dev))
+    model.eval()
+    x = torch.randn(2, 3, 40, 25, 2, generator=g).to(dev)
+    with torch.no_grad():
+        monkeypatch.setenv('AGCN_INFER_FOLD', '0')
+        ref = model(x)
+        monkeypatch.setenv('AGCN_INFER_FOLD', '1')
+        out = model(x)
+        h = torch.randn(4, 64, 40, 25, generator=g).to(dev)
+        model.l2(h)
+        last = lib.load().agcn_last_kernel().decode()
+    scale = max(1.0, float(ref.abs().max()))
+    err = float((out - ref).abs().max()) / scale
+    assert err < 1e-4, err
+    assert 'conv' in last and 'bn_' not in last, last
