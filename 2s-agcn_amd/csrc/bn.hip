@@ -129,27 +129,32 @@ bn_bwd_reduce_kernel(const float* __restrict__ dout, const float* __restrict__ m
   const float* a = y1 + row * P;
   const float* b = HAS2 ? y2 + row * P : nullptr;
   float s0 = 0.f, s1 = 0.f, s2 = 0.f;
-  const int P4 = ((P & 3) == 0) ? (P >> 2) : 0;        // rows are 16-byte aligned when P is a multiple of 4: float4 path
+  // 16-byte loads for every row length: rows of P % 4 != 0 floats (T = 150, 75) start 4- or 8-byte aligned only, which
+  // the loads tolerate; the last P % 4 elements go through the scalar tail below
+  typedef float4 float4_u __attribute__((aligned(4)));
+  const int P4 = P >> 2;
   for (int q4 = threadIdx.x; q4 < P4; q4 += 256) {
-    const float4 d4 = reinterpret_cast<const float4*>(d)[q4];
-    const float4 a4 = reinterpret_cast<const float4*>(a)[q4];
+    const float4 d4 = reinterpret_cast<const float4_u*>(d)[q4];
+    const float4 a4 = reinterpret_cast<const float4_u*>(a)[q4];
     float dv[4] = {d4.x, d4.y, d4.z, d4.w};
     const float av[4] = {a4.x, a4.y, a4.z, a4.w};
     if (mk) {
-      const float4 m4 = reinterpret_cast<const float4*>(mk)[q4];
+      const float4 m4 = reinterpret_cast<const float4_u*>(mk)[q4];
       const float mv[4] = {m4.x, m4.y, m4.z, m4.w};
 #pragma unroll
       for (int k = 0; k < 4; ++k) dv[k] = (mv[k] > 0.f) ? dv[k] : 0.f;
     }
     if (mb) {
       const long e = e_row + 4L * q4;
-      const unsigned nib = mb[e >> 5] >> (e & 31);
+      const int sh = (int)(e & 31);
+      unsigned nib = mb[e >> 5] >> sh;
+      if (sh > 28) nib |= mb[(e >> 5) + 1] << (32 - sh);   // the 4 bits straddle two words (rows not a multiple of 4)
 #pragma unroll
       for (int k = 0; k < 4; ++k) dv[k] = ((nib >> k) & 1u) ? dv[k] : 0.f;
     }
     float bv[4] = {0.f, 0.f, 0.f, 0.f};
     if (HAS2) {
-      const float4 b4 = reinterpret_cast<const float4*>(b)[q4];
+      const float4 b4 = reinterpret_cast<const float4_u*>(b)[q4];
       bv[0] = b4.x; bv[1] = b4.y; bv[2] = b4.z; bv[3] = b4.w;
     }
 #pragma unroll
