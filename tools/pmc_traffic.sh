@@ -11,3 +11,5 @@ rm -rf $OUT && mkdir -p $OUT
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/fetch -- python3 tools/pmc_roofline.py > $OUT/fetch.log 2>&1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/write -- python3 tools/pmc_roofline.py > $OUT/write.log 2>&1
 python3 tools/pmc_parse.py $OUT/fetch $OUT/write gpurun_out/pmc_traffic.json
+# in place for the bench runs that follow in the same box session (and copied back with gpurun_out/)
+cp gpurun_out/pmc_traffic.json profiles/pmc_traffic.json
