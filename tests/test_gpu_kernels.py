@@ -413,3 +413,73 @@ def test_stc_attention_gates_fwd_bwd(case):
     for a, b in zip(pg, par):
         den = max(1e-30, float(b.grad.abs().max()))
         assert float((a.grad.double().cpu() - b.grad).abs().max()) / den < 2e-4, (tuple(b.shape),)
+
+
+INFER_GCN_CASES = [
+    # N, C, Cout, T, V, conv `down`
+    (2, 64, 64, 23, 25, False),
+    (2, 64, 128, 21, 25, True),
+    (2, 128, 128, 12, 18, False),
+    (2, 128, 256, 9, 25, True),
+]
+
+
+@pytest.mark.parametrize('case', INFER_GCN_CASES)
+def test_gcn_unit_infer(case):
+    """y = relu(bias + sum_i W_i (x . adj_i) + residual), residual = x (identity `down`) or a folded 1x1 conv on x that
+    runs as extra plain stages of the same kernel (BN-folded inference, reference agcn.py:103-109 in eval mode)."""
+    from agcn_amd import ops
+    dev = _gpu()
+    N, C, Cout, T, V, has_down = case
+    g = torch.Generator().manual_seed(23 + C + T)
+    x = rnd(g, N, C, T, V)
+    adj = rnd(g, N, 3, V, V, scale=0.3)
+    wcat = rnd(g, Cout, 3 * C, scale=1.0 / np.sqrt(3 * C))
+    bias = rnd(g, Cout, scale=0.1)
+    y_ref = _gcn_ref(x, adj, wcat, bias)
+    if has_down:
+        w2 = rnd(g, Cout, C, scale=1.0 / np.sqrt(C))
+        y_ref = y_ref + torch.einsum('oc,nctv->notv', w2, x)
+    else:
+        y_ref = y_ref + x
+    y_ref = torch.relu(y_ref)
+    xg, ag, wg, bg = [t.float().to(dev) for t in (x, adj, wcat, bias)]
+    if has_down:
+        y = ops.gcn_unit_infer(xg, ag, wg, bg, x2=xg, w2=w2.float().to(dev).contiguous())
+    else:
+        y = ops.gcn_unit_infer(xg, ag, wg, bg, res=xg)
+    if y is None:
+        pytest.skip("fused inference kernels not available in this AGCN_GEMM mode")
+    assert rel(y, y_ref) < TOL
+
+
+INFER_CONV_CASES = [
+    # N, Cin, Cout, T, V, stride, residual, relu
+    (2, 64, 64, 23, 25, 1, True, True),
+    (3, 64, 128, 21, 25, 2, True, True),
+    (2, 128, 128, 12, 25, 1, False, False),
+    (2, 256, 256, 9, 18, 1, True, True),
+]
+
+
+@pytest.mark.parametrize('case', INFER_CONV_CASES)
+def test_conv9_infer(case):
+    """y = act(b + conv9x1(x) [+ res]): unit_tcn + the TCN_GCN_unit tail with the BatchNorm folded (agcn.py:48-50,127-129)."""
+    from agcn_amd import ops
+    dev = _gpu()
+    N, Cin, Cout, T, V, stride, has_res, relu = case
+    g = torch.Generator().manual_seed(29 + Cin + T)
+    x = rnd(g, N, Cin, T, V)
+    w = rnd(g, Cout, Cin, 9, 1, scale=1.0 / np.sqrt(9 * Cin))
+    b = rnd(g, Cout, scale=0.1)
+    y_ref = F.conv2d(x, w, b, stride=(stride, 1), padding=(4, 0))
+    res = rnd(g, *y_ref.shape) if has_res else None
+    if has_res:
+        y_ref = y_ref + res
+    if relu:
+        y_ref = torch.relu(y_ref)
+    y = ops.conv9_infer(x.float().to(dev), w.float().to(dev), b.float().to(dev),
+                        None if res is None else res.float().to(dev), relu=relu, stride=stride)
+    if y is None:
+        pytest.skip("fused inference kernels not available in this AGCN_GEMM mode")
+    assert rel(y, y_ref) < TOL
