@@ -253,10 +253,13 @@ __global__ void __launch_bounds__(NW * 64, 2) gcn_chain_kernel(const ChainArgs a
 
   float xo[BCH ? 1 : VS];
   bf16x8 xq[2][3];                                     // split chain: this lane's x fragments (ks, plane)
+  long long tk0 = 0, tk_stage = 0, tk_mat = 0, tk_bar = 0;   // AGCN_GC_DBG & 8: cycles of wave 0 per section
+  const long long tk_begin = (a.dbg & 8) ? clock64() : 0;
   for (int s = 0; s < S; ++s) {
     const bool plain = s >= S1;
     const int cb = plain ? 0 : s / 3, i = plain ? 0 : s - cb * 3;
     f32x16 d;
+    if (a.dbg & 8) tk0 = clock64();
     if (plain) {
       // Plain stage: the B operand is the staged chunk itself (register j of lane (h, v) = channel c_j + 4h), no
       // aggregation.  Every wave takes its 16 values first; only then may the next chunk overwrite the buffer.
@@ -276,6 +279,7 @@ __global__ void __launch_bounds__(NW * 64, 2) gcn_chain_kernel(const ChainArgs a
       if (i == 0 && cb + 1 < nchunks) issue_X(cb + 1);
       if (i == 2 && cb + 1 == a.ncb && cb + 2 < nchunks) issue_X(cb + 2);   // second plain chunk: one stage ahead
     }
+    if (a.dbg & 8) { const long long t = clock64(); tk_stage += t - tk0; tk0 = t; }
     if (fvalid && !(a.dbg & 1)) {
       if (!plain) {
         // ---- 1. G = X[cb] . A^_i for this wave's frame ----
@@ -377,8 +381,11 @@ __global__ void __launch_bounds__(NW * 64, 2) gcn_chain_kernel(const ChainArgs a
         __builtin_amdgcn_sched_group_barrier(0x008, 6, 0);
       }
     }
+    if (a.dbg & 8) { const long long t = clock64(); tk_mat += t - tk0; tk0 = t; }
     __syncthreads();
+    if (a.dbg & 8) { const long long t = clock64(); tk_bar += t - tk0; }
   }
+  const long long tk_loop_end = (a.dbg & 8) ? clock64() : 0;
 
   // ---- epilogue: the block's (BM x FT*V) tile goes through LDS so that every row is stored (and its residual /
   // accumulate operands loaded) as one contiguous run; a row belongs to one wave, which also reduces its
@@ -466,6 +473,13 @@ __global__ void __launch_bounds__(NW * 64, 2) gcn_chain_kernel(const ChainArgs a
         if (q < xlen) a.out[base + q] = v;
       }
     }
+  }
+  if ((a.dbg & 8) && blockIdx.x == gridDim.x / 2 && tid == 0) {
+    const long long tk_end = clock64();
+    float* o = a.out + ((long)n * a.M + m0) * P + (long)t0 * V;   // (debug run: overwrites 8 outputs of this tile)
+    o[0] = (float)(tk_loop_end - tk_begin); o[1] = (float)tk_stage; o[2] = (float)tk_mat; o[3] = (float)tk_bar;
+    o[4] = (float)(tk_end - tk_loop_end); o[5] = (float)S;
+    o[6] = -12345.f;
   }
 }
 
