@@ -325,7 +325,7 @@ int agcn_bn_act_fwd(const float* y1, const float* scale1, const float* shift1, c
                     void* stream) {
   if (!y1 || !scale1 || !shift1 || !out || N <= 0 || C <= 0 || P <= 0) return AGCN_ERR_ARG;
   const long total = (long)N * C * P;
-  if (total % 4 != 0 || total / 4 > 0x7fffffffL) return AGCN_ERR_UNSUPPORTED;
+  if (total % 4 != 0 || total > 0xffffffffL) return AGCN_ERR_UNSUPPORTED;   // (element indices are 32-bit in the kernels)
   if (res_mode != 0 && !r) return AGCN_ERR_ARG;
   if (res_mode == 2 && (!scale2 || !shift2)) return AGCN_ERR_ARG;
   const unsigned t4 = (unsigned)(total / 4);
@@ -370,7 +370,7 @@ int agcn_bn_bwd_apply(const float* part, int nrows, double count, float param_gr
     return AGCN_ERR_ARG;
   if (y2 && (!gamma2 || !mean2 || !invstd2 || !dy2 || !dgamma2 || !dbeta2)) return AGCN_ERR_ARG;
   const long total = (long)N * C * P;
-  if (total % 4 != 0 || total / 4 > 0x7fffffffL) return AGCN_ERR_UNSUPPORTED;
+  if (total % 4 != 0 || total > 0xffffffffL) return AGCN_ERR_UNSUPPORTED;   // (element indices are 32-bit in the kernels)
   hipStream_t s = (hipStream_t)stream;
   hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 63) / 64), dim3(64), 0, s, part, nrows, C, count,
                      param_grad_scale, gamma1, mean1, invstd1, y2 ? gamma2 : nullptr, mean2, invstd2, coef, dgamma1,
