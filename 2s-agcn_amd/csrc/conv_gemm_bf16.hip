@@ -436,8 +436,11 @@ __global__ void __launch_bounds__((8 + NWP) * 64, 3) conv_pc_kernel(const BfArgs
         } else {
           if (tap == 0 && ch + 1 < nchunks) { issue_B(ch + 1); commit_B(Bbase + ((ch + 1) & 1) * B_BYTES); }
         }
-        // the slot of step g+2 is read from the next barrier on: at most the R-3 newer slots may still be in flight
-        asm volatile("s_waitcnt vmcnt(%0)" :: "n"(PPW * (R - 3)) : "memory");
+        // the slot of step g+2 is read from the next barrier on: at most the R-3 NEWER slots may still be in flight.
+        // (vector-memory operations complete in order, so "at most PPW*(R-3) outstanding" implies slot g+2 has landed
+        // only while newer slots keep being issued; in the last R-1 steps nothing newer exists: wait for everything)
+        if (g + R - 1 < G) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(PPW * (R - 3)) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         step_barrier();
       }
     }

@@ -37,6 +37,9 @@ SIGNATURES = {
     "agcn_conv_bwd_weight_workspace": (_Z, [_I, _I, _I, _I, _I, _I, _I]),
     "agcn_conv_bwd_weight": (_I, [_P, _P, _P, _P, _Z, _I, _I, _I, _I, _I, _I, _I, _P]),
     "agcn_gcn_aggregate_project_fwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _Z, _I, _I, _I, _I, _I, _P]),
+    "agcn_gcn_first_supported": (_I, [_I, _I, _I]),
+    "agcn_gcn_first_tiles": (_I, [_I, _I]),
+    "agcn_gcn_first_fwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
     "agcn_gcn_unit_infer_workspace": (_Z, [_I, _I, _I, _I, _I]),
     "agcn_gcn_unit_infer": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _P, _P, _Z, _I, _I, _I, _I, _I, _P]),
     "agcn_conv9_infer": (_I, [_P, _P, _P, _P, _I, _P, _P, _Z, _I, _I, _I, _I, _I, _I, _P]),

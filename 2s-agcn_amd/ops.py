@@ -138,6 +138,28 @@ def adjacency_fused_fwd(x, wab, bab, A, PA, alpha=None, keep_tp=False):
     return (P, adj, tp) if keep_tp else (P, adj)
 
 
+def first_layer_enabled():
+    """AGCN_FIRST_LAYER=0 keeps the 3-channel layer on the generic kernels (A/B)."""
+    return os.environ.get('AGCN_FIRST_LAYER', '1') != '0'
+
+
+def gcn_first_fwd(x, adj, wcat, bias, wdown, bdown, want_stats=False):
+    """First-layer unit_gcn forward (C <= 4): ypre = bias + sum_i Wd_i (x . adj_i) and dpre = bdown + Wdown x with
+    their BatchNorm partials, one pass over x."""
+    N, C, T, V = x.shape
+    Cout = wcat.shape[0]
+    ypre, dpre = _empty((N, Cout, T, V), x), _empty((N, Cout, T, V), x)
+    st = st2 = None
+    if want_stats:
+        nt = _L().agcn_gcn_first_tiles(T, V)
+        st, st2 = _empty((N * nt, 2, Cout), x), _empty((N * nt, 2, Cout), x)
+    wdown2 = wdown.reshape(Cout, C).contiguous()
+    _lib.check(_L().agcn_gcn_first_fwd(_lib.ptr(x), _lib.ptr(adj), _lib.ptr(wcat), _lib.ptr(bias), _lib.ptr(wdown2),
+                                       _lib.ptr(bdown), _lib.ptr(ypre), _lib.ptr(st), _lib.ptr(dpre), _lib.ptr(st2),
+                                       N, C, Cout, T, V, _lib.stream()), "agcn_gcn_first_fwd")
+    return ypre, st, dpre, st2
+
+
 def aggregate_project_fwd(x, adj, wcat, bias, want_stats=False):
     """y = sum_i Wd_i (x . adj_i) + bias ; wcat: (Cout, 3C) = [Wd_0 | Wd_1 | Wd_2]."""
     N, C, T, V = x.shape
@@ -541,10 +563,18 @@ def gcn_forward(c, x, A, PA, wab, bab, wd, bd, bn, down, training, alpha=None, a
     else:
         tp = P = None
         adj = A.unsqueeze(0).expand(N, 3, V, V).contiguous()
-    ypre, st = aggregate_project_fwd(x, adj, wd, bd, want_stats=training)
-    dpre = bn2 = None
+    first = down is not None and first_layer_enabled() and bool(_L().agcn_gcn_first_supported(C, wd.shape[0], V))
+    if first:
+        # 3-channel first layer: aggregate+project and the `down` convolution in one pass over x (csrc/gcn_first.hip)
+        ypre, st, dpre, st2 = gcn_first_fwd(x, adj, wd, bd, down[0], down[1], want_stats=training)
+    else:
+        ypre, st = aggregate_project_fwd(x, adj, wd, bd, want_stats=training)
+    bn2 = None
+    if not first:
+        dpre = None
     if down is not None:
-        dpre, st2 = conv_fwd(x, down[0], down[1], want_stats=training)
+        if not first:
+            dpre, st2 = conv_fwd(x, down[0], down[1], want_stats=training)
         (bn1, bn2), gcount = _bn_coeffs(training, [st, st2], count, [bn, down[2:]], sync, N)
         out, bits = bn_act_fwd(ypre, bn1, dpre, bn2, relu=True, want_bits=True)
     else:

@@ -79,6 +79,16 @@ int agcn_gcn_stats_tiles(int C, int Cout, int T, int V);    /* stats_part slots 
 int agcn_gcn_aggregate_project_fwd(const float* x, const float* adj, const float* wcat, const float* bias, float* y,
                                    float* stats_part, void* workspace, size_t workspace_bytes, int N, int C, int Cout,
                                    int T, int V, void* stream);
+/* ---- unit_gcn forward of the first layer (1..4 input channels) ----------------------------------------------------------
+ * replaces agcn.py:103-105 AND the `down` convolution (agcn.py:74-77, 108) for in_channels = 3 in one pass over x:
+ * ypre = bias + sum_i Wd_i (x . adj_i), dpre = bdown + Wdown x (wdown (Cout, C) row-major or NULL), and the per-tile
+ * (sum, sumsq) partials of both ([N * agcn_gcn_first_tiles][2][Cout], NULL to skip) for agcn_bn_stats_finalize. */
+int agcn_gcn_first_supported(int C, int Cout, int V);
+int agcn_gcn_first_tiles(int T, int V);
+int agcn_gcn_first_fwd(const float* x, const float* adj, const float* wcat, const float* bias, const float* wdown,
+                       const float* bdown, float* ypre, float* ystats, float* dpre, float* dstats, int N, int C, int Cout,
+                       int T, int V, void* stream);
+
 /* ---- BN-folded inference (eval mode) ---------------------------------------------------------------------------------
  * replaces, for model.eval() under no_grad, the whole of unit_gcn.forward after the adjacency (agcn.py:103-109) and of
  * unit_tcn.forward + the TCN_GCN_unit tail (agcn.py:48-50, 127-129): the caller folds every BatchNorm into the weights

@@ -483,3 +483,33 @@ def test_conv9_infer(case):
     if y is None:
         pytest.skip("fused inference kernels not available in this AGCN_GEMM mode")
     assert rel(y, y_ref) < TOL
+
+
+FIRST_CASES = [(8, 3, 64, 300, 25), (3, 3, 64, 23, 25), (2, 3, 64, 37, 18), (2, 2, 48, 11, 20)]
+
+
+@pytest.mark.parametrize('case', FIRST_CASES)
+def test_gcn_first_layer_forward(case):
+    """First-layer unit_gcn forward (3 input channels): aggregate+project and the `down` convolution in one pass, with the
+    (sum, sumsq) partials of both; bitwise reproducible (reference agcn.py:103-108 with in_channels = 3)."""
+    from agcn_amd import ops
+    dev = _gpu()
+    N, C, Cout, T, V = case
+    g = torch.Generator().manual_seed(31 + T + V)
+    x = rnd(g, N, C, T, V)
+    adj = rnd(g, N, 3, V, V, scale=0.3)
+    wcat = rnd(g, Cout, 3 * C, scale=1.0 / np.sqrt(3 * C))
+    bias = rnd(g, Cout, scale=0.1)
+    wdown = rnd(g, Cout, C, 1, 1, scale=1.0 / np.sqrt(C))
+    bdown = rnd(g, Cout, scale=0.1)
+    y_ref = _gcn_ref(x, adj, wcat, bias)
+    d_ref = torch.einsum('oc,nctv->notv', wdown.view(Cout, C), x) + bdown.view(1, -1, 1, 1)
+    args = [t.float().to(dev) for t in (x, adj, wcat, bias, wdown, bdown)]
+    y, st, d, st2 = ops.gcn_first_fwd(*args, want_stats=True)
+    y2, st_b, d2, st2_b = ops.gcn_first_fwd(*args, want_stats=True)
+    assert torch.equal(y, y2) and torch.equal(st, st_b) and torch.equal(d, d2) and torch.equal(st2, st2_b)
+    assert rel(y, y_ref) < TOL and rel(d, d_ref) < TOL
+    for slab, ref in ((st, y_ref), (st2, d_ref)):
+        s = slab.double().sum(0).cpu()
+        assert rel(s[0], ref.detach().sum((0, 2, 3))) < TOL * 10
+        assert rel(s[1], (ref.detach() ** 2).sum((0, 2, 3))) < TOL * 10
