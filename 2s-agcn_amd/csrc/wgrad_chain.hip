@@ -307,7 +307,7 @@ __global__ void __launch_bounds__(NW * 64, 2) wgrad_chain_kernel(const WcArgs a)
 // subset: measured, that variant ran at the memory system's pace); a consumer wave then holds 3*TM accumulator tiles.
 // NRB: 32*TM-row blocks per workgroup (consumer waves = NCB channel blocks x NFG frames x NRB row blocks)
 template <int AGG, int TM, int NCB, int VS, int NRB = 1, int NWC = 8, int NWP = 4>
-__global__ void __launch_bounds__((NWC + NWP) * 64, 3) wgrad_pc_kernel(const WcArgs a) {
+__global__ void __launch_bounds__((NWC + NWP) * 64, (NWC + NWP) / 4) wgrad_pc_kernel(const WcArgs a) {
   constexpr int NTP = NWP * 64, BM = TM * 32 * NRB;
   constexpr int NS = AGG ? 3 : 1;
   constexpr int NFG = NWC / (NCB * NRB);        // frame groups = frames per stage (one frame per consumer wave)
@@ -752,18 +752,18 @@ WcGeom wc_geom_pc(int N, int M, int C, int V, int T_out, bool bch = false) {
   return g;
 }
 
-template <int AGG, int TM, int NCB, int NRB, int VS>
+template <int AGG, int TM, int NCB, int NRB, int VS, int NWP = 4>
 int wc_launch_pc(WcArgs a, void* ws, size_t ws_bytes, int* nslabs_out, hipStream_t stream) {
   const WcGeom g = wc_geom_pc<AGG, TM, NCB, NRB>(a.N, a.M, a.C, a.V, a.T_out, AGG && VS == 0);
   if (g.smem_bytes > 160 * 1024) return AGCN_ERR_UNSUPPORTED;
   if ((size_t)g.nslabs * a.wsize * 4 > ws_bytes) return AGCN_ERR_WORKSPACE;
   a.part = (float*)ws;
   a.ntiles = g.ntiles; a.pairs_per_split = g.pairs_per_split; a.ncg = g.ncg; a.XP = g.XP;
-  auto kern = wgrad_pc_kernel<AGG, TM, NCB, VS, NRB>;
+  auto kern = wgrad_pc_kernel<AGG, TM, NCB, VS, NRB, 8, NWP>;
   static unsigned char lds_ok[AGCN_MAX_DEVICES] = {};
   if (int e = agcn_allow_big_lds_rt(reinterpret_cast<const void*>(kern), lds_ok)) return e;
-  AGCN_NOTE_KERNEL("wgrad_pc_kernel<%d, %d, %d, %d, %d>", AGG, TM, NCB, VS, NRB);
-  hipLaunchKernelGGL(kern, dim3(g.grid_x, g.nsplit), dim3(12 * 64), g.smem_bytes, stream, a);
+  AGCN_NOTE_KERNEL("wgrad_pc_kernel<%d, %d, %d, %d, %d, 8, %d>", AGG, TM, NCB, VS, NRB, NWP);
+  hipLaunchKernelGGL(kern, dim3(g.grid_x, g.nsplit), dim3((8 + NWP) * 64), g.smem_bytes, stream, a);
   *nslabs_out = g.nslabs;
   return agcn_check_launch();
 }
@@ -804,6 +804,12 @@ int wc_dispatch_pc(const WcArgs& a, void* ws, size_t ws_bytes, int* nslabs, hipS
     if (a.C % 128 == 0) return wc_dispatch_pc_vs<1, 2, 4, 1>(a, ws, ws_bytes, nslabs, s);
     return wc_dispatch_pc_vs<1, 2, 2, 2>(a, ws, ws_bytes, nslabs, s);
   } else {
+    // The plain 1x1 gradients are producer-bound (both operands split by the 4 producers).  Up to 192 rows, 8 producer
+    // waves on 64-row blocks (4 waves per SIMD, 128 VGPRs) win: l6 shape 390 -> 322 us; with more rows the extra
+    // passes over x cost more than the producers gain (l9: 628 -> 697 us).  AGCN_WC_NWP8=0 / 1 forces either.
+    static const int nwp8 = getenv("AGCN_WC_NWP8") ? atoi(getenv("AGCN_WC_NWP8")) : -1;
+    if (a.C % 128 == 0 && (nwp8 == 1 || (nwp8 < 0 && a.M > 64 && a.M <= 192)))
+      return wc_launch_pc<0, 2, 4, 1, 1, 8>(a, ws, ws_bytes, nslabs, s);
     if (a.C % 128 == 0) {
       if (a.M > 64) return wc_dispatch_pc_vs<0, 4, 4, 1>(a, ws, ws_bytes, nslabs, s);
       return wc_dispatch_pc_vs<0, 2, 4, 1>(a, ws, ws_bytes, nslabs, s);
@@ -818,8 +824,11 @@ size_t wc_slabs_pc(int N, int M, int C, int V, int T_out) {
     if (C % 128 == 0) return (size_t)wc_geom_pc<1, 2, 4, 1>(N, M, C, V, T_out).nslabs;
     return (size_t)wc_geom_pc<1, 2, 2, 2>(N, M, C, V, T_out).nslabs;
   } else {
-    if (C % 128 == 0)
-      return (size_t)(M > 64 ? wc_geom_pc<0, 4, 4, 1>(N, M, C, V, T_out).nslabs : wc_geom_pc<0, 2, 4, 1>(N, M, C, V, T_out).nslabs);
+    if (C % 128 == 0) {
+      const size_t n4 = (size_t)wc_geom_pc<0, 4, 4, 1>(N, M, C, V, T_out).nslabs;
+      const size_t n2 = (size_t)wc_geom_pc<0, 2, 4, 1>(N, M, C, V, T_out).nslabs;
+      return n4 > n2 ? n4 : n2;
+    }
     return (size_t)wc_geom_pc<0, 2, 2, 2>(N, M, C, V, T_out).nslabs;
   }
 }
