@@ -49,6 +49,47 @@ def _scratch(width, like):
 # thin wrappers (one C entry point each)
 # ------------------------------------------------------------------------------------------------
 
+# ---- side stream for the weight gradients (AGCN_SIDE_STREAM=0 disables): they do not feed the backward's critical path
+# (dx), so they run beside the backward-data kernels and the two fill the tails of each other's grids (+1 % on the
+# training step, same-box A/B; results are bitwise the same: no kernel changes, only their placement) ----
+_SIDE = {}
+
+
+def side_stream_enabled():
+    return os.environ.get('AGCN_SIDE_STREAM', '1') != '0'
+
+
+def _side_run(fn, inputs):
+    """Run fn() on the side stream after everything enqueued so far on the current stream; returns its result.  The
+    caller must _side_join() before the results are consumed on the current stream."""
+    if not side_stream_enabled():
+        return fn()
+    main = torch.cuda.current_stream()
+    dev = main.device_index
+    side = _SIDE.get(dev)
+    if side is None:
+        side = _SIDE[dev] = torch.cuda.Stream(device=dev)
+    side.wait_stream(main)
+    with torch.cuda.stream(side):
+        out = fn()
+    for t in inputs:
+        if t is not None:
+            t.record_stream(side)
+    outs = out if isinstance(out, (tuple, list)) else (out,)
+    for t in outs:
+        if torch.is_tensor(t):
+            t.record_stream(main)
+    return out
+
+
+def _side_join():
+    if side_stream_enabled():
+        main = torch.cuda.current_stream()
+        side = _SIDE.get(main.device_index)
+        if side is not None:
+            main.wait_stream(side)
+
+
 def conv_out_frames(T, taps, stride):
     pad = (taps - 1) // 2
     return (T + 2 * pad - taps) // stride + 1
@@ -598,11 +639,11 @@ def gcn_backward(c, dout, extra_add=None, extra_mask=None):
     Cout = wd.shape[0]
     dypre, dg1, db1, ddpre, dg2, db2 = bn_bwd(dout, c.g_bits, ypre, gamma1, c.g_bn1, dpre, gamma2, c.g_bn2,
                                               sync=c.g_sync, gcount=c.g_count)
-    dwd = project_bwd_weight(dypre, x, adj, Cout)
+    dwd = _side_run(lambda: project_bwd_weight(dypre, x, adj, Cout), (dypre, x, adj))
     dPA = dwab = dbab = dalpha = dtp = None
     if c.g_adaptive:      # adjacency branch first: its dtp rides along in the dx kernel where that is supported
         dPA, dtp, dbab, dalpha, _ = adjacency_bwd(dypre, wd, x, tp, P, c.g_alpha, wab, c.g_bab)
-        dwab = conv_bwd_weight(dtp, x, wab.shape)
+        dwab = _side_run(lambda: conv_bwd_weight(dtp, x, wab.shape), (dtp, x))
     fuse = dtp is not None and fused_bwd_data_supported(x.shape[1], Cout, x.shape[3])
     ftp = dict(dtp=dtp, wab=wab) if fuse else {}
     if dpre is None:      # identity `down`: dx += dout * (out > 0)
@@ -615,8 +656,9 @@ def gcn_backward(c, dout, extra_add=None, extra_mask=None):
     c.g_dalpha = dalpha
     dwdown = None
     if dpre is not None:
-        dwdown = conv_bwd_weight(ddpre, x, wdown.shape)
+        dwdown = _side_run(lambda: conv_bwd_weight(ddpre, x, wdown.shape), (ddpre, x))
         conv_bwd_data(ddpre, wdown, x.shape, out=dx, accumulate=True)
+    _side_join()
     return dx, dPA, dwab, dbab, dwd, dg1, db1, dwdown, dg2, db2
 
 
@@ -645,17 +687,21 @@ def tcn_forward(c, g, w, b, bn, stride, res_x, res, relu, training, sync=None):
     return out
 
 
-def tcn_backward(c, dout):
+def tcn_backward(c, dout, join=True):
     """Returns dg, dw, dgamma, dbeta, (drpre, dw_res, dgamma_res, dbeta_res)."""
     w, gamma1, wres, gamma2 = c.t_params
     mask = c.t_bits if c.t_relu else None
     dzpre, dg1, db1, drpre, dg2, db2 = bn_bwd(dout, mask, c.t_zpre, gamma1, c.t_bn1, c.t_rpre, gamma2, c.t_bn2,
                                               sync=c.t_sync, gcount=c.t_count)
-    dw = conv_bwd_weight(dzpre, c.t_g, w.shape, c.t_stride)
+    t_g, t_stride = c.t_g, c.t_stride
+    dw = _side_run(lambda: conv_bwd_weight(dzpre, t_g, w.shape, t_stride), (dzpre, t_g))
     dg = conv_bwd_data(dzpre, w, c.t_g.shape, c.t_stride)
     dwres = None
     if drpre is not None:
-        dwres = conv_bwd_weight(drpre, c.t_resx, wres.shape, c.t_stride)
+        t_resx = c.t_resx
+        dwres = _side_run(lambda: conv_bwd_weight(drpre, t_resx, wres.shape, t_stride), (drpre, t_resx))
+    if join:
+        _side_join()
     return dg, dw, dg1, db1, drpre, dwres, dg2, db2
 
 
@@ -884,7 +930,7 @@ class TCNGCNUnitFunction(torch.autograd.Function):
         _need_train(ctx.training)
         c = ctx.c
         dout = dout.contiguous()
-        dg, dtw, dtg, dtb, drpre, drw, drg, drb = tcn_backward(c, dout)
+        dg, dtw, dtg, dtb, drpre, drw, drg, drb = tcn_backward(c, dout, join=False)   # (gcn_backward joins)
         if ctx.res_mode == 1:
             gres = gcn_backward(c, dg, extra_add=dout, extra_mask=c.t_bits)
         else:
