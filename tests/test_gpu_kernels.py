@@ -513,3 +513,34 @@ def test_gcn_first_layer_forward(case):
         s = slab.double().sum(0).cpu()
         assert rel(s[0], ref.detach().sum((0, 2, 3))) < TOL * 10
         assert rel(s[1], (ref.detach() ** 2).sum((0, 2, 3))) < TOL * 10
+
+
+def test_producer_consumer_kernels_are_bitwise_reproducible():
+    """The producer / consumer kernels hand tiles over through LDS rings and counted waits: a missing wait shows up as a
+    run-to-run difference, not as a large error.  Repeated launches on the same operands must agree bit for bit (temporal
+    conv forward / backward-data at a 128-row shape, projection and 1x1 weight gradients)."""
+    from agcn_amd import ops
+    dev = _gpu()
+    g = torch.Generator().manual_seed(41)
+    N, C, T, V = 16, 256, 75, 25
+    x = rnd(g, N, C, T, V).float().to(dev)
+    w9 = rnd(g, C, C, 9, 1, scale=1.0 / np.sqrt(9 * C)).float().to(dev)
+    b = rnd(g, C, scale=0.1).float().to(dev)
+    dy = rnd(g, N, C, T, V).float().to(dev)
+    adj = rnd(g, N, 3, V, V, scale=0.3).float().to(dev)
+    w1 = (C // 4 * 6, C, 1, 1)
+    dy1 = rnd(g, N, w1[0], T, V).float().to(dev)
+    junk = torch.empty(64 << 20, device=dev)             # churn the allocator / caches between repeats
+    ref = None
+    for rep in range(6):
+        junk.normal_()
+        cur = (ops.conv_fwd(x, w9, b, 1, want_stats=True)[0],
+               ops.conv_bwd_data(dy, w9, (N, C, T, V), 1),
+               ops.project_bwd_weight(dy, x, adj, C),
+               ops.conv_bwd_weight(dy1, x, w1, 1))
+        torch.cuda.synchronize()
+        if ref is None:
+            ref = [t.clone() for t in cur]
+        else:
+            for k, (a_, b_) in enumerate(zip(ref, cur)):
+                assert torch.equal(a_, b_), f'output {k} differs in repeat {rep}'
