@@ -45,6 +45,7 @@ struct BfArgs {
   int off_bias;                // byte offset of the bias row in LDS
   int dbg;                     // profiling switches (AGCN_CB_DBG): 1 = no MFMA loop, 2 = stage chunk 0 only, 4 = no epilogue
   int relu;                    // epilogue: out = max(., 0) (BN-folded inference)
+  const float* in_absmax;      // f16x3: max |in| (device scalar written by absmax_kernel): range scaling of the activations
 };
 
 struct BfPackArgs {
@@ -71,8 +72,65 @@ __device__ __forceinline__ void split_pair(float a, float b, unsigned& ph, unsig
   pl = pack_bf16(ra - lo_as_f32(pm), rb - hi_as_f32(pm));
 }
 
+// ---- "f16x3": two fp16 pieces per operand, x = h1 + h2 (11 + 11 significand bits), and the three products h1*h1 +
+// h1*h2 + h2*h1 on v_mfma_f32_32x32x16_f16: dropped terms below 2^-22 |a*b|.  Emulated on the CPU against fp64
+// (tools/split_numerics.py): 9e-7 of the result scale for O(1) operands, the same as an fp32 GEMM's own rounding (7e-7);
+// half the matrix work, half the split arithmetic and two thirds of the LDS bytes of bf16x6.  fp16's RANGE makes it
+// unfit for unscaled gradient operands (1e-6: error 2e-2), so only the FORWARD temporal convolution uses it: its
+// operands are post-BatchNorm activations and weights. ----
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void split_pair_f16(float a, float b, unsigned& p1, unsigned& p2) {
+  const f32x2 v = {a, b};
+  const f16x2 h = __builtin_convertvector(v, f16x2);            // v_cvt_pk_f16_f32 (round to nearest even)
+  const f32x2 r = v - __builtin_convertvector(h, f32x2);
+  p1 = __builtin_bit_cast(unsigned, h);
+  p2 = __builtin_bit_cast(unsigned, __builtin_convertvector(r, f16x2));
+}
+template <bool F16>
+__device__ __forceinline__ f32x16 mfma_split(bf16x8 x, bf16x8 y, f32x16 c) {
+  if constexpr (F16)
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, x), __builtin_bit_cast(f16x8, y), c, 0, 0, 0);
+  else
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(x, y, c, 0, 0, 0);
+}
+
+// fp16 holds |x| < 65504: when the activations' maximum reaches 2^15 the f16x3 kernels multiply them by a power of two
+// (exact) that brings it into [2^14, 2^15) and undo it on the accumulators (exact); small elements then lose bits only
+// below 2^-25 of the tensor's maximum.  (s, 1/s) from the device scalar max |x|.
+__device__ __forceinline__ void f16_range_scale(const float* absmax, float& s, float& inv) {
+  s = 1.f; inv = 1.f;
+  if (absmax) {
+    const float m = *absmax;
+    if (!(m < 32768.f)) {
+      const int e = (int)((__builtin_bit_cast(unsigned, m) >> 23) & 0xffu) - 127;   // floor(log2 m); inf / nan: 128
+      s = __builtin_bit_cast(float, (unsigned)(127 - (e - 14)) << 23);
+      inv = __builtin_bit_cast(float, (unsigned)(127 + (e - 14)) << 23);
+    }
+  }
+}
+
+// max |x| of a tensor -> *out (as the bit pattern of a non-negative float: unsigned order = float order); *out zeroed first
+__global__ void __launch_bounds__(256) absmax_kernel(const float* __restrict__ x, long n, unsigned* __restrict__ out) {
+  __shared__ unsigned red[4];
+  unsigned m = 0;
+  const long n4 = n >> 2;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
+    const f32x4 v = reinterpret_cast<const f32x4*>(x)[i];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) m = max(m, __builtin_bit_cast(unsigned, v[k]) & 0x7fffffffu);
+  }
+  for (long i = (n4 << 2) + (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256)
+    m = max(m, __builtin_bit_cast(unsigned, x[i]) & 0x7fffffffu);
+#pragma unroll
+  for (int k = 32; k >= 1; k >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, k));
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) atomicMax(out, max(max(red[0], red[1]), max(red[2], red[3])));
+}
+
 // wp[(mb*nchunks + ch)][plane][tap][h][ml][8]
-template <int TAPS, int BM>
+template <int TAPS, int BM, bool F16 = false>
 __global__ void __launch_bounds__(256) pack_weights_bf16_kernel(const BfPackArgs p) {
   constexpr int PER_PLANE = TAPS * 2 * BM * 8;
   const int ch = blockIdx.x % p.nchunks, mb = blockIdx.x / p.nchunks;
@@ -90,8 +148,9 @@ __global__ void __launch_bounds__(256) pack_weights_bf16_kernel(const BfPackArgs
       const int kc = ch * CK + h * 8 + j + q;
       v[q] = (m < p.M && kc < p.Kinner) ? p.w[(long)m * p.sa_m + (long)kc * p.sa_c + gt] : 0.f;
     }
-    unsigned ph, pm, pl;
-    split_pair(v[0], v[1], ph, pm, pl);
+    unsigned ph, pm, pl = 0;
+    if constexpr (F16) split_pair_f16(v[0], v[1], ph, pm);
+    else split_pair(v[0], v[1], ph, pm, pl);
     const int o = ((tap * 2 + h) * BM + ml) * 8 + j;
     *reinterpret_cast<unsigned*>(dst + 0 * PER_PLANE + o) = ph;
     *reinterpret_cast<unsigned*>(dst + 1 * PER_PLANE + o) = pm;
@@ -102,7 +161,7 @@ __global__ void __launch_bounds__(256) pack_weights_bf16_kernel(const BfPackArgs
 // NPL = 3: bf16x6 (fp32-equivalent) ; NPL = 2: bf16x3.  WQ = 64-row blocks per staging quarter (2: windows <= 512 rows)
 // TN = 32-position tiles per wave (2: 64-row blocks cover 512 positions, so every weight fragment feeds two MFMAs and
 // the 8-frame halo of the window is amortised over 20 frames instead of 10)
-template <int TAPS, int NPL, int WQ, int TM, int TN = 1>
+template <int TAPS, int NPL, int WQ, int TM, int TN = 1, bool F16 = false>
 __global__ void __launch_bounds__(NT, (TAPS == 1 && TM == 2 && TN == 1) ? 4 : 2) conv_gemm_bf16_kernel(const BfArgs a) {
   constexpr int BM = TM * 32;
   constexpr int A_PLANE = TAPS * 2 * BM * 16;          // bytes per plane of the A image
@@ -127,6 +186,8 @@ __global__ void __launch_bounds__(NT, (TAPS == 1 && TM == 2 && TN == 1) ? 4 : 2)
   const int f0 = t0 * a.src_stride + a.f_off;
   const int WL = a.FW * V, WLR = a.WLR;
   const int g0 = f0 * V;
+  float rs_s = 1.f, rs_inv = 1.f;                      // f16x3 range scale of the activations
+  if constexpr (F16) f16_range_scale(a.in_absmax, rs_s, rs_inv);
 
   int boff[TN];                           // this wave's TN x 32 positions
 #pragma unroll
@@ -189,8 +250,9 @@ __global__ void __launch_bounds__(NT, (TAPS == 1 && TM == 2 && TN == 1) ? 4 : 2)
       for (int c = 0; c < 4; ++c) {
         const float x0 = (okp && (kc0 + 2 * c) < a.Kinner) ? rb[u][2 * c] : 0.f;
         const float x1 = (okp && (kc0 + 2 * c + 1) < a.Kinner) ? rb[u][2 * c + 1] : 0.f;
-        unsigned a0, a1, a2;
-        split_pair(x0, x1, a0, a1, a2);
+        unsigned a0, a1, a2 = 0;
+        if constexpr (F16) split_pair_f16(x0 * rs_s, x1 * rs_s, a0, a1);
+        else split_pair(x0, x1, a0, a1, a2);
         ph[c] = a0; pm[c] = a1; pl[c] = a2;
       }
       if (rr < qlen && r < WL) {
@@ -241,15 +303,15 @@ __global__ void __launch_bounds__(NT, (TAPS == 1 && TM == 2 && TN == 1) ? 4 : 2)
         for (int tn = 0; tn < TN; ++tn) {
           // smallest products first
           if (NPL == 3) {
-            acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afc[NPL - 1], bfc[0][tn], acc[tm][tn], 0, 0, 0);
-            acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afc[0], bfc[NPL - 1][tn], acc[tm][tn], 0, 0, 0);
-            acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afc[NPL >= 2 ? 1 : 0], bfc[NPL >= 2 ? 1 : 0][tn], acc[tm][tn], 0, 0, 0);
+            acc[tm][tn] = mfma_split<F16>(afc[NPL - 1], bfc[0][tn], acc[tm][tn]);
+            acc[tm][tn] = mfma_split<F16>(afc[0], bfc[NPL - 1][tn], acc[tm][tn]);
+            acc[tm][tn] = mfma_split<F16>(afc[NPL >= 2 ? 1 : 0], bfc[NPL >= 2 ? 1 : 0][tn], acc[tm][tn]);
           }
           if (NPL >= 2) {
-            acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afc[NPL >= 2 ? 1 : 0], bfc[0][tn], acc[tm][tn], 0, 0, 0);
-            acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afc[0], bfc[NPL >= 2 ? 1 : 0][tn], acc[tm][tn], 0, 0, 0);
+            acc[tm][tn] = mfma_split<F16>(afc[NPL >= 2 ? 1 : 0], bfc[0][tn], acc[tm][tn]);
+            acc[tm][tn] = mfma_split<F16>(afc[0], bfc[NPL >= 2 ? 1 : 0][tn], acc[tm][tn]);
           }
-          acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afc[0], bfc[0][tn], acc[tm][tn], 0, 0, 0);
+          acc[tm][tn] = mfma_split<F16>(afc[0], bfc[0][tn], acc[tm][tn]);
         }
         // pin the order "reads of the next step, then this step's MFMAs" (the scheduler otherwise sinks the reads to
         // their uses and waits for each)
@@ -278,7 +340,7 @@ __global__ void __launch_bounds__(NT, (TAPS == 1 && TM == 2 && TN == 1) ? 4 : 2)
     for (int tn = 0; tn < TN; ++tn)
 #pragma unroll
       for (int j = 0; j < 16; ++j)
-        tile[(tm * 32 + mfma_row(j, h)) * TP + (wave * TN + tn) * 32 + lr] = acc[tm][tn][j];
+        tile[(tm * 32 + mfma_row(j, h)) * TP + (wave * TN + tn) * 32 + lr] = F16 ? acc[tm][tn][j] * rs_inv : acc[tm][tn][j];
   __syncthreads();
   int poff[4 * TN];
 #pragma unroll
@@ -308,7 +370,8 @@ __global__ void __launch_bounds__(NT, (TAPS == 1 && TM == 2 && TN == 1) ? 4 : 2)
 //     written to the other of two window buffers.
 // Only the producers have vector-memory operations in flight, so the consumers' LDS reads never wait on a vmcnt.
 // One barrier per step.  The ring slot of step g is (g mod R).
-template <int TAPS, int NPL, int R, int NWP = 4>
+// F16: the planes are fp16 pieces (NPL = 2, three products): forward convolution only
+template <int TAPS, int NPL, int R, int NWP = 4, bool F16 = false>
 __global__ void __launch_bounds__((8 + NWP) * 64, 3) conv_pc_kernel(const BfArgs a) {
   constexpr int TM = 4, BM = 128, NWC = 8, NTALL = (NWC + NWP) * 64, NTP = NWP * 64;
   constexpr int SLOT = NPL * 2 * BM * 16;               // bytes of one step's weight image [plane][h][m][8]
@@ -336,6 +399,8 @@ __global__ void __launch_bounds__((8 + NWP) * 64, 3) conv_pc_kernel(const BfArgs
   const int WL = a.FW * V;
   const int nchunks = a.nchunks;
   const int G = nchunks * TAPS;
+  float rs_s = 1.f, rs_inv = 1.f;                      // f16x3 range scale of the activations
+  if constexpr (F16) f16_range_scale(a.in_absmax, rs_s, rs_inv);
 
   float* bias_s = reinterpret_cast<float*>(smem + a.off_bias);
   for (int e = threadIdx.x; e < BM; e += NTALL) bias_s[e] = (a.bias && m0 + e < a.M) ? a.bias[m0 + e] : 0.f;
@@ -402,8 +467,9 @@ __global__ void __launch_bounds__((8 + NWP) * 64, 3) conv_pc_kernel(const BfArgs
           u32x4 ph, pm, pl;
 #pragma unroll
           for (int c = 0; c < 4; ++c) {
-            unsigned q0, q1, q2;
-            split_pair(rb[k][2 * c][e], rb[k][2 * c + 1][e], q0, q1, q2);
+            unsigned q0, q1, q2 = 0;
+            if constexpr (F16) split_pair_f16(rb[k][2 * c][e] * rs_s, rb[k][2 * c + 1][e] * rs_s, q0, q1);
+            else split_pair(rb[k][2 * c][e], rb[k][2 * c + 1][e], q0, q1, q2);
             ph[c] = q0; pm[c] = q1; pl[c] = q2;
           }
           const int r = r0 + e;
@@ -494,15 +560,15 @@ __global__ void __launch_bounds__((8 + NWP) * 64, 3) conv_pc_kernel(const BfArgs
           else load_b(bfn, Bn, 0);
         }
         if (NPL == 3) {
-          acc[tm] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afc[NPL - 1], bfc[0], acc[tm], 0, 0, 0);
-          acc[tm] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afc[0], bfc[NPL - 1], acc[tm], 0, 0, 0);
-          acc[tm] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afc[NPL >= 2 ? 1 : 0], bfc[NPL >= 2 ? 1 : 0], acc[tm], 0, 0, 0);
+          acc[tm] = mfma_split<F16>(afc[NPL - 1], bfc[0], acc[tm]);
+          acc[tm] = mfma_split<F16>(afc[0], bfc[NPL - 1], acc[tm]);
+          acc[tm] = mfma_split<F16>(afc[NPL >= 2 ? 1 : 0], bfc[NPL >= 2 ? 1 : 0], acc[tm]);
         }
         if (NPL >= 2) {
-          acc[tm] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afc[NPL >= 2 ? 1 : 0], bfc[0], acc[tm], 0, 0, 0);
-          acc[tm] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afc[0], bfc[NPL >= 2 ? 1 : 0], acc[tm], 0, 0, 0);
+          acc[tm] = mfma_split<F16>(afc[NPL >= 2 ? 1 : 0], bfc[0], acc[tm]);
+          acc[tm] = mfma_split<F16>(afc[0], bfc[NPL >= 2 ? 1 : 0], acc[tm]);
         }
-        acc[tm] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afc[0], bfc[0], acc[tm], 0, 0, 0);
+        acc[tm] = mfma_split<F16>(afc[0], bfc[0], acc[tm]);
         __builtin_amdgcn_sched_group_barrier(0x100, NPL, 0);
         if (tm + 1 == TM) __builtin_amdgcn_sched_group_barrier(0x100, NPL, 0);
         __builtin_amdgcn_sched_group_barrier(0x008, NMF, 0);
@@ -523,7 +589,7 @@ __global__ void __launch_bounds__((8 + NWP) * 64, 3) conv_pc_kernel(const BfArgs
 #pragma unroll
   for (int tm = 0; tm < TM; ++tm)
 #pragma unroll
-    for (int j = 0; j < 16; ++j) tile[(tm * 32 + mfma_row(j, h)) * TP + wave * 32 + lr] = acc[tm][j];
+    for (int j = 0; j < 16; ++j) tile[(tm * 32 + mfma_row(j, h)) * TP + wave * 32 + lr] = F16 ? acc[tm][j] * rs_inv : acc[tm][j];
   __syncthreads();
   int poff[4];
 #pragma unroll
@@ -541,7 +607,7 @@ __global__ void __launch_bounds__((8 + NWP) * 64, 3) conv_pc_kernel(const BfArgs
 }
 
 // slot-major weight images for conv_pc_kernel: wp[(mb*nchunks + ch)*TAPS + tap][plane][h][ml][8]
-template <int TAPS, int BM, int NPL>
+template <int TAPS, int BM, int NPL, bool F16 = false>
 __global__ void __launch_bounds__(256) pack_weights_slots_kernel(const BfPackArgs p) {
   constexpr int PLANE = 2 * BM * 8;                    // bf16 elements of one plane of a slot
   const int tap = blockIdx.x % TAPS;
@@ -559,8 +625,9 @@ __global__ void __launch_bounds__(256) pack_weights_slots_kernel(const BfPackArg
       const int kc = ch * CK + h * 8 + j + q;
       v[q] = (m < p.M && kc < p.Kinner) ? p.w[(long)m * p.sa_m + (long)kc * p.sa_c + gt] : 0.f;
     }
-    unsigned ph, pm, pl;
-    split_pair(v[0], v[1], ph, pm, pl);
+    unsigned ph, pm, pl = 0;
+    if constexpr (F16) split_pair_f16(v[0], v[1], ph, pm);
+    else split_pair(v[0], v[1], ph, pm, pl);
     const int o = (h * BM + ml) * 8 + j;
     *reinterpret_cast<unsigned*>(dst + 0 * PLANE + o) = ph;
     if (NPL >= 2) *reinterpret_cast<unsigned*>(dst + 1 * PLANE + o) = pm;
@@ -598,6 +665,7 @@ BfGeom bf_geometry(int V, int T_out, int src_stride, int M, int Kinner) {
 
 struct BfProblem {
   BfArgs a;
+  int fwd_f16;                 // forward convolution: the f16x3 arithmetic may be used
   const float* w;
   long sa_m, sa_c;
   int tap_mul, tap_add, tap_flip_from;
@@ -605,7 +673,7 @@ struct BfProblem {
   size_t ws_bytes;
 };
 
-template <int TAPS, int NPL, int WQ, int TM, int TN = 1>
+template <int TAPS, int NPL, int WQ, int TM, int TN = 1, bool F16 = false>
 int launch_bf(BfProblem& p, hipStream_t stream) {
   constexpr int BM = TM * 32;
   BfArgs a = p.a;
@@ -623,14 +691,15 @@ int launch_bf(BfProblem& p, hipStream_t stream) {
     pk.w = p.w; pk.wp = (unsigned short*)p.ws; pk.M = a.M; pk.Kinner = a.Kinner; pk.nchunks = g.nchunks;
     pk.sa_m = p.sa_m; pk.sa_c = p.sa_c;
     pk.tap_mul = p.tap_mul; pk.tap_add = p.tap_add; pk.tap_flip_from = p.tap_flip_from;
-    hipLaunchKernelGGL((pack_weights_bf16_kernel<TAPS, BM>), dim3(g.nmb * g.nchunks), dim3(256), 0, stream, pk);
+    hipLaunchKernelGGL((pack_weights_bf16_kernel<TAPS, BM, F16>), dim3(g.nmb * g.nchunks), dim3(256), 0, stream, pk);
     int rc = agcn_check_launch();
     if (rc) return rc;
   }
-  auto kern = conv_gemm_bf16_kernel<TAPS, NPL, WQ, TM, TN>;
+  auto kern = conv_gemm_bf16_kernel<TAPS, NPL, WQ, TM, TN, F16>;
   static unsigned char lds_ok[AGCN_MAX_DEVICES] = {};   // per (kernel instantiation, device): the attribute is per device
   if (int e = agcn_allow_big_lds_rt(reinterpret_cast<const void*>(kern), lds_ok)) return e;
-  AGCN_NOTE_KERNEL("conv_gemm_bf16_kernel<%d, %d, %d, %d, %d>", TAPS, NPL, WQ, TM, TN);
+  AGCN_NOTE_KERNEL(F16 ? "conv_gemm_bf16_kernel<%d, %d, %d, %d, %d, f16x3>" : "conv_gemm_bf16_kernel<%d, %d, %d, %d, %d>", TAPS, NPL, WQ, TM,
+                   TN);
   hipLaunchKernelGGL(kern, dim3((unsigned)(a.N * g.ntiles * g.nmb)), dim3(NT), g.smem_bytes, stream, a);
   return agcn_check_launch();
 }
@@ -669,7 +738,7 @@ static inline bool conv_pc_enabled() {
   return v == 1;
 }
 
-template <int TAPS, int NPL, int R = 5, int NWP = 4>
+template <int TAPS, int NPL, int R = 5, int NWP = 4, bool F16 = false>
 int launch_pc(BfProblem& p, hipStream_t stream) {
   constexpr int BM = 128;
   BfArgs a = p.a;
@@ -683,15 +752,15 @@ int launch_pc(BfProblem& p, hipStream_t stream) {
   pk.w = p.w; pk.wp = (unsigned short*)p.ws; pk.M = a.M; pk.Kinner = a.Kinner; pk.nchunks = g.nchunks;
   pk.sa_m = p.sa_m; pk.sa_c = p.sa_c;
   pk.tap_mul = p.tap_mul; pk.tap_add = p.tap_add; pk.tap_flip_from = p.tap_flip_from;
-  hipLaunchKernelGGL((pack_weights_slots_kernel<TAPS, BM, NPL>), dim3(g.nmb * g.nchunks * TAPS), dim3(256), 0, stream, pk);
+  hipLaunchKernelGGL((pack_weights_slots_kernel<TAPS, BM, NPL, F16>), dim3(g.nmb * g.nchunks * TAPS), dim3(256), 0, stream, pk);
   int rc = agcn_check_launch();
   if (rc) return rc;
-  auto kern = conv_pc_kernel<TAPS, NPL, R, NWP>;
+  auto kern = conv_pc_kernel<TAPS, NPL, R, NWP, F16>;
   static unsigned char lds_ok[AGCN_MAX_DEVICES] = {};
   if (int e = agcn_allow_big_lds_rt(reinterpret_cast<const void*>(kern), lds_ok)) return e;
   static const int dbg = getenv("AGCN_CB_DBG") ? atoi(getenv("AGCN_CB_DBG")) : 0;
   a.dbg = dbg;
-  AGCN_NOTE_KERNEL("conv_pc_kernel<%d, %d, %d, %d>", TAPS, NPL, R, NWP);
+  AGCN_NOTE_KERNEL(F16 ? "conv_pc_kernel<%d, %d, %d, %d, f16x3>" : "conv_pc_kernel<%d, %d, %d, %d>", TAPS, NPL, R, NWP);
   hipLaunchKernelGGL(kern, dim3((unsigned)(a.N * g.ntiles * g.nmb)), dim3((8 + NWP) * 64), g.smem_bytes, stream, a);
   return agcn_check_launch();
 }
@@ -713,7 +782,20 @@ int launch_npl(BfProblem& p, int npl, hipStream_t s) {
     if (pc_applies<TAPS>(p, npl)) {
       static const int nwp2 = getenv("AGCN_CONV_NWP2") ? atoi(getenv("AGCN_CONV_NWP2")) : 0;
       if (nwp2) return launch_pc<TAPS, 3, 5, 2>(p, s);
+      if constexpr (TAPS == 9) {
+        if (p.fwd_f16) return launch_pc<TAPS, 2, 5, 4, true>(p, s);
+      }
       return launch_pc<TAPS, 3>(p, s);
+    }
+  }
+  if constexpr (TAPS == 9) {
+    if (p.fwd_f16) {      // forward convolution on f16x3 (three fp16 products), same tiles
+      if (p.a.M % 128 == 0 && fits128) return launch_bf<TAPS, 2, WQ, 4, 1, true>(p, s);
+      if (agcn_bf16_conv_wide(TAPS, p.a.M)) {
+        const int rc = launch_bf<TAPS, 2, 3, 2, 2, true>(p, s);
+        if (rc != AGCN_ERR_UNSUPPORTED) return rc;
+      }
+      return launch_bf<TAPS, 2, WQ, 2, 1, true>(p, s);
     }
   }
   if (p.a.M % 128 == 0 && fits128) {
@@ -756,6 +838,20 @@ int agcn_bf16_conv9_fwd(const float* x, const float* w, const float* bias, float
   BfProblem p = {};
   BfArgs& a = p.a;
   a.in = x; a.bias = bias; a.out = y; a.stats = stats_part; a.add1 = add; a.relu = relu;
+  {   // AGCN_CONV_F16X3=0 keeps the forward on bf16x6
+    static const int f16x3 = getenv("AGCN_CONV_F16X3") ? atoi(getenv("AGCN_CONV_F16X3")) : 1;
+    p.fwd_f16 = f16x3 && npl == 3;
+  }
+  if (p.fwd_f16) {
+    // max |x| for the range scale: the last 16 bytes of the workspace (its size carries 256 bytes of slack)
+    if (ws_bytes < 64) return AGCN_ERR_WORKSPACE;
+    unsigned* amax = reinterpret_cast<unsigned*>(static_cast<char*>(ws) + ((ws_bytes - 16) & ~(size_t)15));
+    if (hipMemsetAsync(amax, 0, 4, s) != hipSuccess) return AGCN_ERR_ARG;
+    hipLaunchKernelGGL(absmax_kernel, dim3(2048), dim3(256), 0, s, x, (long)N * Cin * T * V, amax);
+    if (int rc = agcn_check_launch()) return rc;
+    a.in_absmax = reinterpret_cast<const float*>(amax);
+    ws_bytes = (ws_bytes - 16) & ~(size_t)15;
+  }
   a.N = N; a.M = Cout; a.Kinner = Cin; a.in_rows = Cin; a.V = V;
   a.T_src = T; a.T_out = (T + 8 - 9) / stride + 1; a.T_full = a.T_out;
   a.src_stride = stride; a.f_off = -4; a.out_fs = 1; a.out_fo = 0;
