@@ -95,15 +95,17 @@ __device__ __forceinline__ f32x16 mfma_split(bf16x8 x, bf16x8 y, f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x16_bf16(x, y, c, 0, 0, 0);
 }
 
-// fp16 holds |x| < 65504: when the activations' maximum reaches 2^15 the f16x3 kernels multiply them by a power of two
-// (exact) that brings it into [2^14, 2^15) and undo it on the accumulators (exact); small elements then lose bits only
-// below 2^-25 of the tensor's maximum.  (s, 1/s) from the device scalar max |x|.
+// fp16 holds 6e-5 < |x| < 65504 with full precision: the f16x3 kernels multiply the streamed operand by the power of two
+// (exact) that brings the TENSOR's maximum into [2^14, 2^15) and undo it on the accumulators (exact).  That covers
+// activations that grew past 2^15 as well as gradients of 1e-6; elements far below the maximum lose bits only below
+// 2^-25 of it, which is what an fp32 accumulation of the same sum loses too.  (s, 1/s) from the device scalar max |x|.
 __device__ __forceinline__ void f16_range_scale(const float* absmax, float& s, float& inv) {
   s = 1.f; inv = 1.f;
   if (absmax) {
     const float m = *absmax;
-    if (!(m < 32768.f)) {
-      const int e = (int)((__builtin_bit_cast(unsigned, m) >> 23) & 0xffu) - 127;   // floor(log2 m); inf / nan: 128
+    if (m > 0.f) {
+      int e = (int)((__builtin_bit_cast(unsigned, m) >> 23) & 0xffu) - 127;   // floor(log2 m); inf / nan: 128
+      e = max(e, -100);
       s = __builtin_bit_cast(float, (unsigned)(127 - (e - 14)) << 23);
       inv = __builtin_bit_cast(float, (unsigned)(127 + (e - 14)) << 23);
     }
@@ -665,7 +667,7 @@ BfGeom bf_geometry(int V, int T_out, int src_stride, int M, int Kinner) {
 
 struct BfProblem {
   BfArgs a;
-  int fwd_f16;                 // forward convolution: the f16x3 arithmetic may be used
+  int fwd_f16;                 // use the f16x3 arithmetic (a.in_absmax holds the streamed operand's max)
   const float* w;
   long sa_m, sa_c;
   int tap_mul, tap_add, tap_flip_from;
@@ -782,14 +784,12 @@ int launch_npl(BfProblem& p, int npl, hipStream_t s) {
     if (pc_applies<TAPS>(p, npl)) {
       static const int nwp2 = getenv("AGCN_CONV_NWP2") ? atoi(getenv("AGCN_CONV_NWP2")) : 0;
       if (nwp2) return launch_pc<TAPS, 3, 5, 2>(p, s);
-      if constexpr (TAPS == 9) {
-        if (p.fwd_f16) return launch_pc<TAPS, 2, 5, 4, true>(p, s);
-      }
+      if (p.fwd_f16) return launch_pc<TAPS, 2, 5, 4, true>(p, s);
       return launch_pc<TAPS, 3>(p, s);
     }
   }
-  if constexpr (TAPS == 9) {
-    if (p.fwd_f16) {      // forward convolution on f16x3 (three fp16 products), same tiles
+  if constexpr (TAPS >= 3) {
+    if (p.fwd_f16) {      // f16x3 (three fp16 products), same tiles
       if (p.a.M % 128 == 0 && fits128) return launch_bf<TAPS, 2, WQ, 4, 1, true>(p, s);
       if (agcn_bf16_conv_wide(TAPS, p.a.M)) {
         const int rc = launch_bf<TAPS, 2, 3, 2, 2, true>(p, s);
@@ -866,6 +866,20 @@ int agcn_bf16_conv9_bwd_data(const float* dy, const float* w, float* dx, int acc
                              int N, int Cin, int Cout, int T, int V, int stride, int npl, hipStream_t s) {
   BfProblem p = {};
   BfArgs& a = p.a;
+  {   // f16x3 with the gradient normalised by its maximum (AGCN_CONV_F16X3=0: bf16x6)
+    static const int f16x3 = getenv("AGCN_CONV_F16X3") ? atoi(getenv("AGCN_CONV_F16X3")) : 1;
+    p.fwd_f16 = f16x3 && npl == 3;
+  }
+  if (p.fwd_f16) {
+    if (ws_bytes < 64) return AGCN_ERR_WORKSPACE;
+    unsigned* amax = reinterpret_cast<unsigned*>(static_cast<char*>(ws) + ((ws_bytes - 16) & ~(size_t)15));
+    if (hipMemsetAsync(amax, 0, 4, s) != hipSuccess) return AGCN_ERR_ARG;
+    const int To = (T + 8 - 9) / stride + 1;
+    hipLaunchKernelGGL(absmax_kernel, dim3(2048), dim3(256), 0, s, dy, (long)N * Cout * To * V, amax);
+    if (int rc = agcn_check_launch()) return rc;
+    a.in_absmax = reinterpret_cast<const float*>(amax);
+    ws_bytes = (ws_bytes - 16) & ~(size_t)15;
+  }
   a.in = dy; a.out = dx; a.accumulate = accumulate;
   a.add1 = add1; a.mask1 = mask1; a.add2 = add2; a.mask2 = mask2;
   a.N = N; a.M = Cin; a.Kinner = Cout; a.in_rows = Cout; a.V = V;
