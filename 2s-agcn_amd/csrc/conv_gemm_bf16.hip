@@ -700,8 +700,7 @@ int launch_bf(BfProblem& p, hipStream_t stream) {
   auto kern = conv_gemm_bf16_kernel<TAPS, NPL, WQ, TM, TN, F16>;
   static unsigned char lds_ok[AGCN_MAX_DEVICES] = {};   // per (kernel instantiation, device): the attribute is per device
   if (int e = agcn_allow_big_lds_rt(reinterpret_cast<const void*>(kern), lds_ok)) return e;
-  AGCN_NOTE_KERNEL(F16 ? "conv_gemm_bf16_kernel<%d, %d, %d, %d, %d, f16x3>" : "conv_gemm_bf16_kernel<%d, %d, %d, %d, %d>", TAPS, NPL, WQ, TM,
-                   TN);
+  AGCN_NOTE_KERNEL("conv_gemm_bf16_kernel<%d, %d, %d, %d, %d, %s>", TAPS, NPL, WQ, TM, TN, F16 ? "true" : "false");
   hipLaunchKernelGGL(kern, dim3((unsigned)(a.N * g.ntiles * g.nmb)), dim3(NT), g.smem_bytes, stream, a);
   return agcn_check_launch();
 }
@@ -762,7 +761,7 @@ int launch_pc(BfProblem& p, hipStream_t stream) {
   if (int e = agcn_allow_big_lds_rt(reinterpret_cast<const void*>(kern), lds_ok)) return e;
   static const int dbg = getenv("AGCN_CB_DBG") ? atoi(getenv("AGCN_CB_DBG")) : 0;
   a.dbg = dbg;
-  AGCN_NOTE_KERNEL(F16 ? "conv_pc_kernel<%d, %d, %d, %d, f16x3>" : "conv_pc_kernel<%d, %d, %d, %d>", TAPS, NPL, R, NWP);
+  AGCN_NOTE_KERNEL("conv_pc_kernel<%d, %d, %d, %d, %s>", TAPS, NPL, R, NWP, F16 ? "true" : "false");   // (as rocprofv3 prints it)
   hipLaunchKernelGGL(kern, dim3((unsigned)(a.N * g.ntiles * g.nmb)), dim3((8 + NWP) * 64), g.smem_bytes, stream, a);
   return agcn_check_launch();
 }
