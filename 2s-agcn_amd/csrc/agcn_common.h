@@ -59,10 +59,11 @@ size_t agcn_bf16_conv_workspace(int Cin, int Cout, int T, int V, int stride);
 bool agcn_bf16_conv_wide(int taps, int M);
 int agcn_bf16_conv9_fwd(const float* x, const float* w, const float* bias, float* y, float* stats_part, void* ws,
                         size_t ws_bytes, int N, int Cin, int Cout, int T, int V, int stride, int npl, hipStream_t s,
-                        const float* add = nullptr, int relu = 0);
+                        const float* add = nullptr, int relu = 0, const float* x_absmax = nullptr);
 int agcn_bf16_conv9_bwd_data(const float* dy, const float* w, float* dx, int accumulate, const float* add1,
                              const float* mask1, const float* add2, const float* mask2, void* ws, size_t ws_bytes,
-                             int N, int Cin, int Cout, int T, int V, int stride, int npl, hipStream_t s);
+                             int N, int Cin, int Cout, int T, int V, int stride, int npl, hipStream_t s,
+                             const float* dy_absmax = nullptr);
 
 size_t agcn_bf16_conv1_workspace(int Cin, int Cout, int T, int V, int stride);
 int agcn_bf16_conv1_fwd(const float* x, const float* w, const float* bias, float* y, float* stats_part, void* ws,

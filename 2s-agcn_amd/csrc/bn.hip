@@ -77,7 +77,9 @@ template <int RES, bool RELU>
 __global__ void __launch_bounds__(256)
 bn_act_fwd_kernel(const float4* __restrict__ y1, const float* __restrict__ scale1, const float* __restrict__ shift1,
                   const float4* __restrict__ r, const float* __restrict__ scale2, const float* __restrict__ shift2,
-                  float4* __restrict__ out, unsigned* __restrict__ bits, unsigned total4, unsigned P, unsigned C) {
+                  float4* __restrict__ out, unsigned* __restrict__ bits, unsigned total4, unsigned P, unsigned C,
+                  unsigned* __restrict__ amax) {
+  unsigned tmax = 0;                     // max |out| of this thread (bit pattern: unsigned order = float order)
   // block-uniform trip count: the sign-mask words are assembled with shuffles over groups of 8 lanes (32 elements)
   for (unsigned i0 = blockIdx.x * blockDim.x; i0 < total4; i0 += gridDim.x * blockDim.x) {
     const unsigned i = i0 + threadIdx.x;
@@ -103,6 +105,10 @@ bn_act_fwd_kernel(const float4* __restrict__ y1, const float* __restrict__ scale
       ov[k] = RELU ? fmaxf(v, 0.f) : v;
     }
     if (valid) out[i] = make_float4(ov[0], ov[1], ov[2], ov[3]);
+    if (amax && valid) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) tmax = max(tmax, __float_as_uint(ov[k]) & 0x7fffffffu);
+    }
     if (bits) {
       // bit e of word w <-> element 32*w + e is positive: what every backward pass needs of `out`, 32x smaller
       unsigned nib = valid ? ((ov[0] > 0.f) | ((ov[1] > 0.f) << 1) | ((ov[2] > 0.f) << 2) | ((ov[3] > 0.f) << 3)) : 0u;
@@ -111,6 +117,17 @@ bn_act_fwd_kernel(const float4* __restrict__ y1, const float* __restrict__ scale
       w |= __shfl_xor(w, 2);
       w |= __shfl_xor(w, 4);
       if ((threadIdx.x & 7u) == 0u && valid) bits[e0 >> 5] = w;
+    }
+  }
+  if (amax) {                            // by-product for the f16x3 kernels that read `out`: the tensor's max |x|
+#pragma unroll
+    for (int k = 32; k >= 1; k >>= 1) tmax = max(tmax, (unsigned)__shfl_xor((int)tmax, k));
+    __shared__ unsigned wmax[4];           // one atomic per workgroup (<= 4096 per launch)
+    if ((threadIdx.x & 63u) == 0u) wmax[threadIdx.x >> 6] = tmax;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      const unsigned m = max(max(wmax[0], wmax[1]), max(wmax[2], wmax[3]));
+      if (m) atomicMax(amax, m);
     }
   }
 }
@@ -229,7 +246,8 @@ __global__ void __launch_bounds__(256)
 bn_bwd_apply_kernel(const float4* __restrict__ dout, const float4* __restrict__ mask, int mask_bits,
                     const float4* __restrict__ y1,
                     const float4* __restrict__ y2, const float* __restrict__ coef, float4* __restrict__ dy1,
-                    float4* __restrict__ dy2, unsigned total4, unsigned P, unsigned C) {
+                    float4* __restrict__ dy2, unsigned total4, unsigned P, unsigned C, unsigned* __restrict__ amax1) {
+  unsigned tmax = 0;
   for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += gridDim.x * blockDim.x) {
     const unsigned e0 = i * 4u;
     const unsigned row = e0 / P;
@@ -264,6 +282,21 @@ bn_bwd_apply_kernel(const float4* __restrict__ dout, const float4* __restrict__ 
     }
     dy1[i] = make_float4(o1[0], o1[1], o1[2], o1[3]);
     if (HAS2) dy2[i] = make_float4(o2[0], o2[1], o2[2], o2[3]);
+    if (amax1) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) tmax = max(tmax, __float_as_uint(o1[k]) & 0x7fffffffu);
+    }
+  }
+  if (amax1) {                           // max |dy1| for the f16x3 kernels that read it
+#pragma unroll
+    for (int k = 32; k >= 1; k >>= 1) tmax = max(tmax, (unsigned)__shfl_xor((int)tmax, k));
+    __shared__ unsigned wmax[4];
+    if ((threadIdx.x & 63u) == 0u) wmax[threadIdx.x >> 6] = tmax;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      const unsigned m = max(max(wmax[0], wmax[1]), max(wmax[2], wmax[3]));
+      if (m) atomicMax(amax1, m);
+    }
   }
 }
 
@@ -320,10 +353,21 @@ int agcn_bn_eval_coeff(const float* gamma, const float* beta, const float* runni
 }
 
 // res_mode: 0 none, 1 identity residual r, 2 BN'd residual branch scale2*r+shift2 ; total = N*C*P must be %4
+int agcn_bn_act_fwd_ex(const float* y1, const float* scale1, const float* shift1, const float* r, const float* scale2,
+                       const float* shift2, float* out, unsigned* sign_bits, float* absmax_out, int N, int C, int P,
+                       int res_mode, int relu, void* stream);
 int agcn_bn_act_fwd(const float* y1, const float* scale1, const float* shift1, const float* r, const float* scale2,
                     const float* shift2, float* out, unsigned* sign_bits, int N, int C, int P, int res_mode, int relu,
                     void* stream) {
+  return agcn_bn_act_fwd_ex(y1, scale1, shift1, r, scale2, shift2, out, sign_bits, nullptr, N, C, P, res_mode, relu, stream);
+}
+
+// same; absmax_out (optional, 4 bytes): max |out| as a float, for the split-fp16 kernels that read `out` next
+int agcn_bn_act_fwd_ex(const float* y1, const float* scale1, const float* shift1, const float* r, const float* scale2,
+                       const float* shift2, float* out, unsigned* sign_bits, float* absmax_out, int N, int C, int P,
+                       int res_mode, int relu, void* stream) {
   if (!y1 || !scale1 || !shift1 || !out || N <= 0 || C <= 0 || P <= 0) return AGCN_ERR_ARG;
+  if (absmax_out && hipMemsetAsync(absmax_out, 0, 4, (hipStream_t)stream) != hipSuccess) return AGCN_ERR_ARG;
   const long total = (long)N * C * P;
   if (total % 4 != 0 || total > 0xffffffffL) return AGCN_ERR_UNSUPPORTED;   // (element indices are 32-bit in the kernels)
   if (res_mode != 0 && !r) return AGCN_ERR_ARG;
@@ -333,7 +377,7 @@ int agcn_bn_act_fwd(const float* y1, const float* scale1, const float* shift1, c
   const dim3 g(ew_grid(t4)), b(256);
 #define LAUNCH_ACT(R, A)                                                                                       \
   hipLaunchKernelGGL((bn_act_fwd_kernel<R, A>), g, b, 0, s, (const float4*)y1, scale1, shift1, (const float4*)r, \
-                     scale2, shift2, (float4*)out, sign_bits, t4, (unsigned)P, (unsigned)C)
+                     scale2, shift2, (float4*)out, sign_bits, t4, (unsigned)P, (unsigned)C, (unsigned*)absmax_out)
   if (relu) {
     if (res_mode == 0) LAUNCH_ACT(0, true); else if (res_mode == 1) LAUNCH_ACT(1, true); else LAUNCH_ACT(2, true);
   } else {
@@ -361,11 +405,28 @@ int agcn_bn_bwd_reduce(const float* dout, const void* mask, int mask_bits, const
   return agcn_check_launch();
 }
 
+int agcn_bn_bwd_apply_ex(const float* part, int nrows, double count, float param_grad_scale, const float* dout,
+                         const void* mask, int mask_bits, const float* y1, const float* gamma1, const float* mean1,
+                         const float* invstd1, const float* y2, const float* gamma2, const float* mean2,
+                         const float* invstd2, float* coef, float* dy1, float* dgamma1, float* dbeta1, float* dy2,
+                         float* dgamma2, float* dbeta2, float* absmax1_out, int N, int C, int P, void* stream);
 int agcn_bn_bwd_apply(const float* part, int nrows, double count, float param_grad_scale, const float* dout,
                       const void* mask, int mask_bits, const float* y1, const float* gamma1, const float* mean1, const float* invstd1,
                       const float* y2, const float* gamma2, const float* mean2, const float* invstd2, float* coef,
                       float* dy1, float* dgamma1, float* dbeta1, float* dy2, float* dgamma2, float* dbeta2, int N, int C,
                       int P, void* stream) {
+  return agcn_bn_bwd_apply_ex(part, nrows, count, param_grad_scale, dout, mask, mask_bits, y1, gamma1, mean1, invstd1, y2,
+                              gamma2, mean2, invstd2, coef, dy1, dgamma1, dbeta1, dy2, dgamma2, dbeta2, nullptr, N, C, P,
+                              stream);
+}
+
+// same; absmax1_out (optional, 4 bytes): max |dy1| as a float, for the split-fp16 kernels that read dy1 next
+int agcn_bn_bwd_apply_ex(const float* part, int nrows, double count, float param_grad_scale, const float* dout,
+                         const void* mask, int mask_bits, const float* y1, const float* gamma1, const float* mean1,
+                         const float* invstd1, const float* y2, const float* gamma2, const float* mean2,
+                         const float* invstd2, float* coef, float* dy1, float* dgamma1, float* dbeta1, float* dy2,
+                         float* dgamma2, float* dbeta2, float* absmax1_out, int N, int C, int P, void* stream) {
+  if (absmax1_out && hipMemsetAsync(absmax1_out, 0, 4, (hipStream_t)stream) != hipSuccess) return AGCN_ERR_ARG;
   if (!part || !dout || !y1 || !gamma1 || !mean1 || !invstd1 || !coef || !dy1 || !dgamma1 || !dbeta1 || nrows <= 0)
     return AGCN_ERR_ARG;
   if (y2 && (!gamma2 || !mean2 || !invstd2 || !dy2 || !dgamma2 || !dbeta2)) return AGCN_ERR_ARG;
@@ -382,11 +443,11 @@ int agcn_bn_bwd_apply(const float* part, int nrows, double count, float param_gr
   if (y2)
     hipLaunchKernelGGL(bn_bwd_apply_kernel<true>, g, b, 0, s, (const float4*)dout, (const float4*)mask, mask_bits,
                        (const float4*)y1, (const float4*)y2, (const float*)coef, (float4*)dy1, (float4*)dy2, t4,
-                       (unsigned)P, (unsigned)C);
+                       (unsigned)P, (unsigned)C, (unsigned*)absmax1_out);
   else
     hipLaunchKernelGGL(bn_bwd_apply_kernel<false>, g, b, 0, s, (const float4*)dout, (const float4*)mask, mask_bits,
                        (const float4*)y1, (const float4*)y2, (const float*)coef, (float4*)dy1, (float4*)dy2, t4,
-                       (unsigned)P, (unsigned)C);
+                       (unsigned)P, (unsigned)C, (unsigned*)absmax1_out);
   return agcn_check_launch();
 }
 

@@ -618,16 +618,28 @@ int agcn_gcn_stats_tiles(int C, int Cout, int T, int V) {
 }
 
 // y[n][o][t,v] = bias[o] + sum_{c,k} w[o][c][k] x[n][c][(t*stride + k - pad), v]      (unit_tcn conv, 1x1 convs)
+int agcn_conv_fwd_ex(const float* x, const float* w, const float* bias, float* y, float* stats_part, void* workspace,
+                     size_t workspace_bytes, int N, int Cin, int Cout, int T, int V, int taps, int stride,
+                     const float* x_absmax, void* stream);
 int agcn_conv_fwd(const float* x, const float* w, const float* bias, float* y, float* stats_part, void* workspace,
                   size_t workspace_bytes, int N, int Cin, int Cout, int T, int V, int taps, int stride,
                   void* stream) {
+  return agcn_conv_fwd_ex(x, w, bias, y, stats_part, workspace, workspace_bytes, N, Cin, Cout, T, V, taps, stride, nullptr,
+                          stream);
+}
+
+// same; x_absmax (optional): device scalar max |x| left by agcn_bn_act_fwd_ex when it produced x -- saves the split-fp16
+// temporal convolution its own pass over x for the range scale
+int agcn_conv_fwd_ex(const float* x, const float* w, const float* bias, float* y, float* stats_part, void* workspace,
+                     size_t workspace_bytes, int N, int Cin, int Cout, int T, int V, int taps, int stride,
+                     const float* x_absmax, void* stream) {
   if (!x || !w || !y || !workspace || N <= 0 || Cin <= 0 || Cout <= 0 || T <= 0 || V <= 0 || V > 32)
     return AGCN_ERR_ARG;
   if ((taps != 1 && taps != 9) || (stride != 1 && stride != 2)) return AGCN_ERR_UNSUPPORTED;
   const int pad = (taps - 1) / 2;
   if (taps == 9 && agcn_gemm_precision() != 0)
     return agcn_bf16_conv9_fwd(x, w, bias, y, stats_part, workspace, workspace_bytes, N, Cin, Cout, T, V, stride,
-                               agcn_gemm_precision(), (hipStream_t)stream);
+                               agcn_gemm_precision(), (hipStream_t)stream, nullptr, 0, x_absmax);
   Problem p = {};
   ConvGemmArgs& a = p.a;
   a.in = x; a.bias = bias; a.out = y; a.stats = stats_part;
@@ -643,17 +655,30 @@ int agcn_conv_fwd(const float* x, const float* w, const float* bias, float* y, f
 }
 
 // dx[n][c][t,v] (+)= sum_{o,k} w[o][c][k] dy[n][o][(t + pad - k)/stride, v]  (+ masked addends)
+int agcn_conv_bwd_data_ex(const float* dy, const float* w, float* dx, int accumulate, const float* add1,
+                          const float* mask1, const float* add2, const float* mask2, void* workspace,
+                          size_t workspace_bytes, int N, int Cin, int Cout, int T, int V, int taps, int stride,
+                          const float* dy_absmax, void* stream);
 int agcn_conv_bwd_data(const float* dy, const float* w, float* dx, int accumulate, const float* add1,
                        const float* mask1, const float* add2, const float* mask2, void* workspace,
                        size_t workspace_bytes, int N, int Cin, int Cout, int T, int V, int taps, int stride,
                        void* stream) {
+  return agcn_conv_bwd_data_ex(dy, w, dx, accumulate, add1, mask1, add2, mask2, workspace, workspace_bytes, N, Cin, Cout, T,
+                               V, taps, stride, nullptr, stream);
+}
+
+// same; dy_absmax (optional): device scalar max |dy| left by agcn_bn_bwd_apply_ex
+int agcn_conv_bwd_data_ex(const float* dy, const float* w, float* dx, int accumulate, const float* add1,
+                          const float* mask1, const float* add2, const float* mask2, void* workspace,
+                          size_t workspace_bytes, int N, int Cin, int Cout, int T, int V, int taps, int stride,
+                          const float* dy_absmax, void* stream) {
   if (!dy || !w || !dx || !workspace || N <= 0 || Cin <= 0 || Cout <= 0 || T <= 0 || V <= 0 || V > 32)
     return AGCN_ERR_ARG;
   if ((taps != 1 && taps != 9) || (stride != 1 && stride != 2)) return AGCN_ERR_UNSUPPORTED;
   const int pad = (taps - 1) / 2;
   if (taps == 9 && agcn_gemm_precision() != 0)
     return agcn_bf16_conv9_bwd_data(dy, w, dx, accumulate, add1, mask1, add2, mask2, workspace, workspace_bytes, N, Cin,
-                                    Cout, T, V, stride, agcn_gemm_precision(), (hipStream_t)stream);
+                                    Cout, T, V, stride, agcn_gemm_precision(), (hipStream_t)stream, dy_absmax);
   // 1x1 backward-data: measured 10-17% faster on the split-bf16 kernel; the 1x1 forward (store-bound) is not
   if (taps == 1 && stride == 1 && agcn_chained() && Cin >= 64 && Cout >= 32)
     return agcn_bf16_conv1_bwd_data(dy, w, dx, accumulate, add1, mask1, add2, mask2, workspace, workspace_bytes, N, Cin,

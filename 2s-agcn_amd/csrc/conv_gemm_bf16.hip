@@ -833,7 +833,7 @@ size_t agcn_bf16_conv_workspace(int Cin, int Cout, int T, int V, int stride) {
 
 int agcn_bf16_conv9_fwd(const float* x, const float* w, const float* bias, float* y, float* stats_part, void* ws,
                         size_t ws_bytes, int N, int Cin, int Cout, int T, int V, int stride, int npl,
-                        hipStream_t s, const float* add, int relu) {
+                        hipStream_t s, const float* add, int relu, const float* x_absmax) {
   BfProblem p = {};
   BfArgs& a = p.a;
   a.in = x; a.bias = bias; a.out = y; a.stats = stats_part; a.add1 = add; a.relu = relu;
@@ -841,7 +841,9 @@ int agcn_bf16_conv9_fwd(const float* x, const float* w, const float* bias, float
     static const int f16x3 = getenv("AGCN_CONV_F16X3") ? atoi(getenv("AGCN_CONV_F16X3")) : 1;
     p.fwd_f16 = f16x3 && npl == 3;
   }
-  if (p.fwd_f16) {
+  if (p.fwd_f16 && x_absmax) {
+    a.in_absmax = x_absmax;                    // left behind by the kernel that produced x (agcn_bn_act_fwd_ex)
+  } else if (p.fwd_f16) {
     // max |x| for the range scale: the last 16 bytes of the workspace (its size carries 256 bytes of slack)
     if (ws_bytes < 64) return AGCN_ERR_WORKSPACE;
     unsigned* amax = reinterpret_cast<unsigned*>(static_cast<char*>(ws) + ((ws_bytes - 16) & ~(size_t)15));
@@ -862,14 +864,17 @@ int agcn_bf16_conv9_fwd(const float* x, const float* w, const float* bias, float
 
 int agcn_bf16_conv9_bwd_data(const float* dy, const float* w, float* dx, int accumulate, const float* add1,
                              const float* mask1, const float* add2, const float* mask2, void* ws, size_t ws_bytes,
-                             int N, int Cin, int Cout, int T, int V, int stride, int npl, hipStream_t s) {
+                             int N, int Cin, int Cout, int T, int V, int stride, int npl, hipStream_t s,
+                             const float* dy_absmax) {
   BfProblem p = {};
   BfArgs& a = p.a;
   {   // f16x3 with the gradient normalised by its maximum (AGCN_CONV_F16X3=0: bf16x6)
     static const int f16x3 = getenv("AGCN_CONV_F16X3") ? atoi(getenv("AGCN_CONV_F16X3")) : 1;
     p.fwd_f16 = f16x3 && npl == 3;
   }
-  if (p.fwd_f16) {
+  if (p.fwd_f16 && dy_absmax) {
+    a.in_absmax = dy_absmax;                   // left behind by agcn_bn_bwd_apply_ex
+  } else if (p.fwd_f16) {
     if (ws_bytes < 64) return AGCN_ERR_WORKSPACE;
     unsigned* amax = reinterpret_cast<unsigned*>(static_cast<char*>(ws) + ((ws_bytes - 16) & ~(size_t)15));
     if (hipMemsetAsync(amax, 0, 4, s) != hipSuccess) return AGCN_ERR_ARG;

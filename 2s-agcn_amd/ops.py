@@ -95,12 +95,17 @@ def _side_join():
             main.wait_stream(side)
 
 
+def fused_amax_enabled():
+    """AGCN_FUSED_AMAX=0: the split-fp16 convolutions compute their operand's maximum in a pass of their own (A/B)."""
+    return os.environ.get('AGCN_FUSED_AMAX', '1') != '0'
+
+
 def conv_out_frames(T, taps, stride):
     pad = (taps - 1) // 2
     return (T + 2 * pad - taps) // stride + 1
 
 
-def conv_fwd(x, w, b, stride=1, want_stats=False):
+def conv_fwd(x, w, b, stride=1, want_stats=False, x_amax=None):
     """y = conv2d(x, w(k,1), b, stride=(s,1), padding=((k-1)/2,0)); optional per-channel (sum,sumsq) partials."""
     N, Cin, T, V = x.shape
     Cout, Cin2, taps, one = w.shape
@@ -112,20 +117,24 @@ def conv_fwd(x, w, b, stride=1, want_stats=False):
         nt = _L().agcn_conv_stats_tiles(Cin, Cout, To, V, taps, stride)
         stats = _empty((N * nt, 2, Cout), x)
     ws, nb = _conv_ws(Cin, Cout, T, V, taps, stride, x)
-    _lib.check(_L().agcn_conv_fwd(_lib.ptr(x), _lib.ptr(w), _lib.ptr(b), _lib.ptr(y), _lib.ptr(stats), ws.data_ptr(),
-                                  nb, N, Cin, Cout, T, V, taps, stride, _lib.stream()), "agcn_conv_fwd")
+    # x_amax: 1-element tensor with max |x| left by bn_act_fwd(..., want_amax=True): the split-fp16 temporal convolution
+    # then skips its own pass over x
+    _lib.check(_L().agcn_conv_fwd_ex(_lib.ptr(x), _lib.ptr(w), _lib.ptr(b), _lib.ptr(y), _lib.ptr(stats), ws.data_ptr(),
+                                     nb, N, Cin, Cout, T, V, taps, stride, _lib.ptr(x_amax), _lib.stream()),
+               "agcn_conv_fwd")
     return y, stats
 
 
 def conv_bwd_data(dy, w, x_shape, stride=1, out=None, accumulate=False, add1=None, mask1=None, add2=None,
-                  mask2=None):
+                  mask2=None, dy_amax=None):
     N, Cin, T, V = x_shape
     Cout, _, taps, _ = w.shape
     dx = out if out is not None else _empty(x_shape, dy)
     ws, nb = _conv_ws(Cin, Cout, T, V, taps, stride, dy)
-    _lib.check(_L().agcn_conv_bwd_data(_lib.ptr(dy), _lib.ptr(w), _lib.ptr(dx), int(accumulate), _lib.ptr(add1),
-                                       _lib.ptr(mask1), _lib.ptr(add2), _lib.ptr(mask2), ws.data_ptr(), nb, N, Cin,
-                                       Cout, T, V, taps, stride, _lib.stream()), "agcn_conv_bwd_data")
+    _lib.check(_L().agcn_conv_bwd_data_ex(_lib.ptr(dy), _lib.ptr(w), _lib.ptr(dx), int(accumulate), _lib.ptr(add1),
+                                          _lib.ptr(mask1), _lib.ptr(add2), _lib.ptr(mask2), ws.data_ptr(), nb, N, Cin,
+                                          Cout, T, V, taps, stride, _lib.ptr(dy_amax), _lib.stream()),
+               "agcn_conv_bwd_data")
     return dx
 
 
@@ -483,7 +492,7 @@ def bn_eval_coeffs(gamma, beta, running_mean, running_var, eps=BN_EPS):
     return st
 
 
-def bn_act_fwd(y1, st1, r=None, st2=None, relu=True, want_bits=False):
+def bn_act_fwd(y1, st1, r=None, st2=None, relu=True, want_bits=False, amax_out=None):
     """out = act(scale1*y1 + shift1 + res); res = 0 (r None) | r (st2 None) | scale2*r + shift2.
     want_bits: also return the sign bit mask of ``out`` (int32 words, 32 elements each) for the BatchNorm backward."""
     N, C, T, V = y1.shape
@@ -492,14 +501,16 @@ def bn_act_fwd(y1, st1, r=None, st2=None, relu=True, want_bits=False):
     out = torch.empty_like(y1)
     bits = torch.empty((y1.numel() + 31) // 32, dtype=torch.int32, device=y1.device) if want_bits else None
     mode = 0 if r is None else (1 if st2 is None else 2)
-    _lib.check(_L().agcn_bn_act_fwd(_lib.ptr(y1), _lib.ptr(st1.scale), _lib.ptr(st1.shift), _lib.ptr(r),
-                                    _lib.ptr(st2.scale) if st2 else None, _lib.ptr(st2.shift) if st2 else None,
-                                    _lib.ptr(out), _lib.ptr_bits(bits), N, C, T * V, mode, int(relu), _lib.stream()),
+    # amax_out: optional 1-element tensor that receives max |out| (for the split-fp16 kernels that read `out` next)
+    _lib.check(_L().agcn_bn_act_fwd_ex(_lib.ptr(y1), _lib.ptr(st1.scale), _lib.ptr(st1.shift), _lib.ptr(r),
+                                       _lib.ptr(st2.scale) if st2 else None, _lib.ptr(st2.shift) if st2 else None,
+                                       _lib.ptr(out), _lib.ptr_bits(bits), _lib.ptr(amax_out), N, C, T * V, mode,
+                                       int(relu), _lib.stream()),
                "agcn_bn_act_fwd")
     return (out, bits) if want_bits else out
 
 
-def bn_bwd(dout, mask, y1, gamma1, st1, y2=None, gamma2=None, st2=None, sync=None, gcount=None):
+def bn_bwd(dout, mask, y1, gamma1, st1, y2=None, gamma2=None, st2=None, sync=None, gcount=None, amax_out=None):
     """Backward through out = relu(bn1(y1) [+ bn2(y2)] [+ identity]) in train mode.  ``mask``: the fp32 output tensor
     (positive elements pass) or the int32 sign bit mask of ``bn_act_fwd(..., want_bits=True)``; None = no ReLU.
     Returns dy1, dgamma1, dbeta1, dy2, dgamma2, dbeta2 (branch-2 entries None without y2)."""
@@ -519,7 +530,17 @@ def bn_bwd(dout, mask, y1, gamma1, st1, y2=None, gamma2=None, st2=None, sync=Non
         dg2, db2 = _empty((C,), y1), _empty((C,), y1)
     mbits = int(mask is not None and mask.dtype == torch.int32)
     mptr = _lib.ptr_bits(mask) if mbits else _lib.ptr(mask)
-    if sync is None:
+    if sync is None and amax_out is not None:
+        # (amax_out: 1-element tensor that receives max |dy1| for the split-fp16 kernels that read dy1 next)
+        _lib.check(_L().agcn_bn_bwd_reduce(_lib.ptr(dout), mptr, mbits, _lib.ptr(y1), _lib.ptr(y2),
+                                           _lib.ptr(part), N, C, T * V, _lib.stream()), "agcn_bn_bwd_reduce")
+        _lib.check(_L().agcn_bn_bwd_apply_ex(
+            _lib.ptr(part), N, float(N) * float(T * V), 1.0, _lib.ptr(dout), mptr, mbits, _lib.ptr(y1),
+            _lib.ptr(gamma1), _lib.ptr(st1.mean), _lib.ptr(st1.invstd), _lib.ptr(y2), _lib.ptr(gamma2),
+            _lib.ptr(st2.mean) if st2 else None, _lib.ptr(st2.invstd) if st2 else None, _lib.ptr(coef), _lib.ptr(dy1),
+            _lib.ptr(dg1), _lib.ptr(db1), _lib.ptr(dy2), _lib.ptr(dg2), _lib.ptr(db2), _lib.ptr(amax_out), N, C, T * V,
+            _lib.stream()), "agcn_bn_bwd_apply")
+    elif sync is None:
         _lib.check(_L().agcn_bn_bwd(
             _lib.ptr(dout), mptr, mbits, _lib.ptr(y1), _lib.ptr(gamma1), _lib.ptr(st1.mean), _lib.ptr(st1.invstd),
             _lib.ptr(y2), _lib.ptr(gamma2), _lib.ptr(st2.mean) if st2 else None, _lib.ptr(st2.invstd) if st2 else None,
@@ -532,12 +553,12 @@ def bn_bwd(dout, mask, y1, gamma1, st1, y2=None, gamma2=None, st2=None, sync=Non
         # gradient average of the data-parallel step restores them (every rank holds the same value)
         sums = _allreduce_sum(_colsum(part, N, 3 * C), sync)
         total = float(gcount) if gcount is not None else float(N * T * V * sync.world)
-        _lib.check(_L().agcn_bn_bwd_apply(
+        _lib.check(_L().agcn_bn_bwd_apply_ex(
             _lib.ptr(sums), 1, total, 1.0 / sync.world, _lib.ptr(dout), mptr, mbits, _lib.ptr(y1),
             _lib.ptr(gamma1), _lib.ptr(st1.mean), _lib.ptr(st1.invstd), _lib.ptr(y2), _lib.ptr(gamma2),
             _lib.ptr(st2.mean) if st2 else None, _lib.ptr(st2.invstd) if st2 else None, _lib.ptr(coef), _lib.ptr(dy1),
-            _lib.ptr(dg1), _lib.ptr(db1), _lib.ptr(dy2), _lib.ptr(dg2), _lib.ptr(db2), N, C, T * V, _lib.stream()),
-            "agcn_bn_bwd_apply")
+            _lib.ptr(dg1), _lib.ptr(db1), _lib.ptr(dy2), _lib.ptr(dg2), _lib.ptr(db2), _lib.ptr(amax_out), N, C, T * V,
+            _lib.stream()), "agcn_bn_bwd_apply")
     if S > 1:                          # the weight / bias are shared by the S virtual sub-batches
         dg1, db1 = dg1.view(S, -1).sum(0), db1.view(S, -1).sum(0)
         if dg2 is not None:
@@ -622,10 +643,12 @@ def gcn_forward(c, x, A, PA, wab, bab, wd, bd, bn, down, training, alpha=None, a
         if not first:
             dpre, st2 = conv_fwd(x, down[0], down[1], want_stats=training)
         (bn1, bn2), gcount = _bn_coeffs(training, [st, st2], count, [bn, down[2:]], sync, N)
-        out, bits = bn_act_fwd(ypre, bn1, dpre, bn2, relu=True, want_bits=True)
+        c.g_amax = _empty((1,), x) if fused_amax_enabled() else None   # max |g| for the temporal convolution that reads g
+        out, bits = bn_act_fwd(ypre, bn1, dpre, bn2, relu=True, want_bits=True, amax_out=c.g_amax)
     else:
         (bn1,), gcount = _bn_coeffs(training, [st], count, [bn], sync, N)
-        out, bits = bn_act_fwd(ypre, bn1, x, None, relu=True, want_bits=True)
+        c.g_amax = _empty((1,), x) if fused_amax_enabled() else None
+        out, bits = bn_act_fwd(ypre, bn1, x, None, relu=True, want_bits=True, amax_out=c.g_amax)
     c.g_sync, c.g_count = sync, gcount
     c.g_bits = bits          # sign bit mask of `out` for the BatchNorm backward (32x less traffic than `out`)
     c.g_x, c.g_tp, c.g_P, c.g_adj, c.g_ypre, c.g_dpre, c.g_out = x, tp, P, adj, ypre, dpre, out
@@ -672,7 +695,8 @@ def tcn_forward(c, g, w, b, bn, stride, res_x, res, relu, training, sync=None):
     relu(tcn(g) + residual(x)) (agcn.py:127-129).  res = None (no residual) | 'identity' |
     (w, b, bn_w, bn_b, bn_rm, bn_rv) for the unit_tcn(kernel_size=1, stride) residual."""
     N, C, T, V = g.shape
-    zpre, st = conv_fwd(g, w, b, stride, want_stats=training)
+    g_amax = getattr(c, 'g_amax', None) if getattr(c, 'g_out', None) is g else None   # only for the tensor it describes
+    zpre, st = conv_fwd(g, w, b, stride, want_stats=training, x_amax=g_amax)
     To = zpre.shape[2]
     count = N * To * V
     rpre = bn2 = None
@@ -696,11 +720,12 @@ def tcn_backward(c, dout, join=True):
     """Returns dg, dw, dgamma, dbeta, (drpre, dw_res, dgamma_res, dbeta_res)."""
     w, gamma1, wres, gamma2 = c.t_params
     mask = c.t_bits if c.t_relu else None
+    dz_amax = _empty((1,), dout) if fused_amax_enabled() else None   # max |dzpre| for the backward-data convolution
     dzpre, dg1, db1, drpre, dg2, db2 = bn_bwd(dout, mask, c.t_zpre, gamma1, c.t_bn1, c.t_rpre, gamma2, c.t_bn2,
-                                              sync=c.t_sync, gcount=c.t_count)
+                                              sync=c.t_sync, gcount=c.t_count, amax_out=dz_amax)
     t_g, t_stride = c.t_g, c.t_stride
     dw = _side_run(lambda: conv_bwd_weight(dzpre, t_g, w.shape, t_stride), (dzpre, t_g))
-    dg = conv_bwd_data(dzpre, w, c.t_g.shape, c.t_stride)
+    dg = conv_bwd_data(dzpre, w, c.t_g.shape, c.t_stride, dy_amax=dz_amax)
     dwres = None
     if drpre is not None:
         t_resx = c.t_resx

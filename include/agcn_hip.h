@@ -79,6 +79,26 @@ int agcn_gcn_stats_tiles(int C, int Cout, int T, int V);    /* stats_part slots 
 int agcn_gcn_aggregate_project_fwd(const float* x, const float* adj, const float* wcat, const float* bias, float* y,
                                    float* stats_part, void* workspace, size_t workspace_bytes, int N, int C, int Cout,
                                    int T, int V, void* stream);
+/* ---- operand maxima for the split-fp16 ("f16x3") temporal convolutions ------------------------------------------------
+ * The f16x3 kernels scale their streamed operand by a power of two derived from the tensor's max |x|.  The
+ * _ex variants let the kernel that PRODUCES a tensor leave that maximum behind (4-byte device scalar) and the kernel that
+ * consumes it skip its own pass over the tensor; with NULL they behave exactly like the plain entry points. */
+int agcn_bn_act_fwd_ex(const float* y1, const float* scale1, const float* shift1, const float* r, const float* scale2,
+                       const float* shift2, float* out, unsigned* sign_bits, float* absmax_out, int N, int C, int P,
+                       int res_mode, int relu, void* stream);
+int agcn_bn_bwd_apply_ex(const float* part, int nrows, double count, float param_grad_scale, const float* dout,
+                         const void* mask, int mask_bits, const float* y1, const float* gamma1, const float* mean1,
+                         const float* invstd1, const float* y2, const float* gamma2, const float* mean2,
+                         const float* invstd2, float* coef, float* dy1, float* dgamma1, float* dbeta1, float* dy2,
+                         float* dgamma2, float* dbeta2, float* absmax1_out, int N, int C, int P, void* stream);
+int agcn_conv_fwd_ex(const float* x, const float* w, const float* bias, float* y, float* stats_part, void* workspace,
+                     size_t workspace_bytes, int N, int Cin, int Cout, int T, int V, int taps, int stride,
+                     const float* x_absmax, void* stream);
+int agcn_conv_bwd_data_ex(const float* dy, const float* w, float* dx, int accumulate, const float* add1,
+                          const float* mask1, const float* add2, const float* mask2, void* workspace,
+                          size_t workspace_bytes, int N, int Cin, int Cout, int T, int V, int taps, int stride,
+                          const float* dy_absmax, void* stream);
+
 /* ---- unit_gcn forward of the first layer (1..4 input channels) ----------------------------------------------------------
  * replaces agcn.py:103-105 AND the `down` convolution (agcn.py:74-77, 108) for in_channels = 3 in one pass over x:
  * ypre = bias + sum_i Wd_i (x . adj_i), dpre = bdown + Wdown x (wdown (Cout, C) row-major or NULL), and the per-tile
