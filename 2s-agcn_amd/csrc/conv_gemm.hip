@@ -559,6 +559,9 @@ const char* agcn_gemm_mode(void) {
   const int m = agcn_gemm_precision();
   return m == 3 ? "bf16x6" : (m == 0 ? "f32" : (m == 1 ? "bf16" : "bf16x3"));
 }
+// arithmetic of unit_gcn's aggregate+project chain (forward and backward-data): "f16x3" in the default fp32-equivalent
+// mode (AGCN_CHAIN_F16X3=0: "bf16x6"), else AGCN_GEMM's mode
+const char* agcn_chain_mode(void) { return agcn_chain_f16x3() ? "f16x3" : agcn_gemm_mode(); }
 int agcn_conv_num_tiles(int V, int T_out) {
   int tt = agcn_conv_tile_frames(V, T_out);
   return (T_out + tt - 1) / tt;

@@ -13,6 +13,7 @@
 // fragment (8 consecutive k for one row/column) is one conflict-free ds_read_b128, and a temporal tap is a row offset.
 #include "agcn_common.h"
 #include "epilogue.h"
+#include "split_f16.h"
 
 namespace {
 
@@ -72,63 +73,14 @@ __device__ __forceinline__ void split_pair(float a, float b, unsigned& ph, unsig
   pl = pack_bf16(ra - lo_as_f32(pm), rb - hi_as_f32(pm));
 }
 
-// ---- "f16x3": two fp16 pieces per operand, x = h1 + h2 (11 + 11 significand bits), and the three products h1*h1 +
-// h1*h2 + h2*h1 on v_mfma_f32_32x32x16_f16: dropped terms below 2^-22 |a*b|.  Emulated on the CPU against fp64
-// (tools/split_numerics.py): 9e-7 of the result scale for O(1) operands, the same as an fp32 GEMM's own rounding (7e-7);
-// half the matrix work, half the split arithmetic and two thirds of the LDS bytes of bf16x6.  fp16's RANGE makes it
-// unfit for unscaled gradient operands (1e-6: error 2e-2), so only the FORWARD temporal convolution uses it: its
-// operands are post-BatchNorm activations and weights. ----
-typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
-typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ void split_pair_f16(float a, float b, unsigned& p1, unsigned& p2) {
-  const f32x2 v = {a, b};
-  const f16x2 h = __builtin_convertvector(v, f16x2);            // v_cvt_pk_f16_f32 (round to nearest even)
-  const f32x2 r = v - __builtin_convertvector(h, f32x2);
-  p1 = __builtin_bit_cast(unsigned, h);
-  p2 = __builtin_bit_cast(unsigned, __builtin_convertvector(r, f16x2));
-}
+// ---- "f16x3" (split_f16.h): the temporal convolutions' forward and backward-data run on it, their streamed operand
+// range-scaled by the tensor maximum ----
 template <bool F16>
 __device__ __forceinline__ f32x16 mfma_split(bf16x8 x, bf16x8 y, f32x16 c) {
   if constexpr (F16)
     return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, x), __builtin_bit_cast(f16x8, y), c, 0, 0, 0);
   else
     return __builtin_amdgcn_mfma_f32_32x32x16_bf16(x, y, c, 0, 0, 0);
-}
-
-// fp16 holds 6e-5 < |x| < 65504 with full precision: the f16x3 kernels multiply the streamed operand by the power of two
-// (exact) that brings the TENSOR's maximum into [2^14, 2^15) and undo it on the accumulators (exact).  That covers
-// activations that grew past 2^15 as well as gradients of 1e-6; elements far below the maximum lose bits only below
-// 2^-25 of it, which is what an fp32 accumulation of the same sum loses too.  (s, 1/s) from the device scalar max |x|.
-__device__ __forceinline__ void f16_range_scale(const float* absmax, float& s, float& inv) {
-  s = 1.f; inv = 1.f;
-  if (absmax) {
-    const float m = *absmax;
-    if (m > 0.f) {
-      int e = (int)((__builtin_bit_cast(unsigned, m) >> 23) & 0xffu) - 127;   // floor(log2 m); inf / nan: 128
-      e = max(e, -100);
-      s = __builtin_bit_cast(float, (unsigned)(127 - (e - 14)) << 23);
-      inv = __builtin_bit_cast(float, (unsigned)(127 + (e - 14)) << 23);
-    }
-  }
-}
-
-// max |x| of a tensor -> *out (as the bit pattern of a non-negative float: unsigned order = float order); *out zeroed first
-__global__ void __launch_bounds__(256) absmax_kernel(const float* __restrict__ x, long n, unsigned* __restrict__ out) {
-  __shared__ unsigned red[4];
-  unsigned m = 0;
-  const long n4 = n >> 2;
-  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
-    const f32x4 v = reinterpret_cast<const f32x4*>(x)[i];
-#pragma unroll
-    for (int k = 0; k < 4; ++k) m = max(m, __builtin_bit_cast(unsigned, v[k]) & 0x7fffffffu);
-  }
-  for (long i = (n4 << 2) + (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256)
-    m = max(m, __builtin_bit_cast(unsigned, x[i]) & 0x7fffffffu);
-#pragma unroll
-  for (int k = 32; k >= 1; k >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, k));
-  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
-  __syncthreads();
-  if (threadIdx.x == 0) atomicMax(out, max(max(red[0], red[1]), max(red[2], red[3])));
 }
 
 // wp[(mb*nchunks + ch)][plane][tap][h][ml][8]

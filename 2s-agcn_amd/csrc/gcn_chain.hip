@@ -14,6 +14,7 @@
 // Pipeline: weight images are double-buffered in LDS; the global loads of stage s+2 (and of the next x chunk) are
 // issued into registers before the matrix-core work of stage s and committed before stage s+1: one barrier per stage.
 #include "agcn_common.h"
+#include "split_f16.h"
 
 namespace {
 
@@ -48,6 +49,8 @@ struct ChainArgs {
   int npl;                     // 3: six split products (bf16x6) ; 1: hi*hi only (bf16)
   int dbg;                     // profiling switches (AGCN_GC_DBG): 1 = no matrix work, 2 = no staging after the prologue
   int relu;                    // epilogue: out = max(., 0) (BN-folded inference)
+  const float* in_absmax;      // f16x3: device scalars max |in|, max |in2| (null: none) for the range scale
+  const float* in2_absmax;
 };
 
 struct ChainPackArgs {
@@ -79,14 +82,16 @@ __host__ __device__ __forceinline__ int chain_channel(int hf, int h, int e) {
 }
 
 // one block per (mblock, cb, i) image: [plane][hf][tm][lane][8]
-template <int TM>
+// F16: two fp16 planes (f16x3) instead of three bf16 planes
+template <int TM, bool F16>
 __global__ void __launch_bounds__(256) chain_pack_kernel(const ChainPackArgs p) {
   constexpr int BM = TM * 32;
-  constexpr int PER_PLANE = 2 * TM * 64 * 8;          // bf16 elements
+  constexpr int PL = F16 ? 2 : 3;
+  constexpr int PER_PLANE = 2 * TM * 64 * 8;          // 16-bit elements
   const int i = blockIdx.x % p.nsub;
   const int cb = (blockIdx.x / p.nsub) % p.ncb;
   const int mb = blockIdx.x / (p.nsub * p.ncb);
-  unsigned short* dst = p.wp + ((long)mb * p.s_total + p.s_off + (long)cb * p.nsub + i) * 3 * PER_PLANE;
+  unsigned short* dst = p.wp + ((long)mb * p.s_total + p.s_off + (long)cb * p.nsub + i) * PL * PER_PLANE;
   for (int e = threadIdx.x; e < PER_PLANE / 2; e += 256) {     // one bf16 pair per iteration
     const int e2 = e & 3;                 // slot pair (2*e2, 2*e2+1)
     const int lane = (e >> 2) & 63;
@@ -100,22 +105,30 @@ __global__ void __launch_bounds__(256) chain_pack_kernel(const ChainPackArgs p) 
       const int c = cb * CB + chain_channel(hf, h, 2 * e2 + q);
       v[q] = (m < p.M && c < p.K) ? p.w[(long)m * p.sa_m + (long)i * p.sa_i + (long)c * p.sa_c] : 0.f;
     }
-    unsigned ph, pm, pl;
-    split_pair(v[0], v[1], ph, pm, pl);
+    unsigned ph, pm, pl = 0;
+    if constexpr (F16) split_pair_f16(v[0], v[1], ph, pm);
+    else split_pair(v[0], v[1], ph, pm, pl);
     const int o = ((hf * TM + tm) * 64 + lane) * 8 + 2 * e2;
     *reinterpret_cast<unsigned*>(dst + 0 * PER_PLANE + o) = ph;
     *reinterpret_cast<unsigned*>(dst + 1 * PER_PLANE + o) = pm;
-    *reinterpret_cast<unsigned*>(dst + 2 * PER_PLANE + o) = pl;
+    if constexpr (!F16) *reinterpret_cast<unsigned*>(dst + 2 * PER_PLANE + o) = pl;
   }
 }
 
 // VS >= (V+1)/2 aggregation steps (13: NTU V=25, 9: Kinetics V=18, 16: any V <= 32; surplus steps multiply zero rows)
 // NW waves per workgroup = frames per workgroup tile (one frame per wave)
-template <int TM, int VS, int NW>
+// F16 (with VS == 0): both contractions on f16x3 (split_f16.h) instead of bf16x6: two fp16 planes per operand, three
+// products; the staged source is multiplied by the power of two that brings max(|in|, |in2|) into [2^8, 2^9) before it
+// is split (so that G = x . A^ stays inside fp16's range for column sums of |A^| up to 2^7) and the accumulators by its
+// inverse in the epilogue.
+template <int TM, int VS, int NW, bool F16 = false>
 __global__ void __launch_bounds__(NW * 64, 2) gcn_chain_kernel(const ChainArgs a) {
+  static_assert(!F16 || VS == 0, "the f16x3 chain runs the aggregation on split MFMA too");
   constexpr int NT = NW * 64, FT = NW;
   constexpr int BM = TM * 32;
-  constexpr int A_IMG = 3 * 2 * TM * 1024;             // bytes of one stage's weight image
+  constexpr int PL = F16 ? 2 : 3;                      // planes per split operand
+  constexpr int NPROD = F16 ? 3 : 6;                   // MFMA products per step
+  constexpr int A_IMG = PL * 2 * TM * 1024;            // bytes of one stage's weight image
   constexpr int A16 = A_IMG / 16;
   constexpr int EA = (A16 + NT - 1) / NT;
   constexpr int XB = FT / 2;                           // 64-float column blocks of a staged x row (V <= 32)
@@ -126,7 +139,7 @@ __global__ void __launch_bounds__(NW * 64, 2) gcn_chain_kernel(const ChainArgs a
   // x fragment (8 consecutive joints of its channel) is split in registers once per channel block and serves all
   // three subsets.
   constexpr bool BCH = (VS == 0);
-  constexpr int ADJ_BYTES = BCH ? 3 * 3 * 2 * 2 * 32 * 16 : 3 * 32 * 32 * 4;
+  constexpr int ADJ_BYTES = BCH ? 3 * PL * 2 * 2 * 32 * 16 : 3 * 32 * 32 * 4;
   float* adjp = reinterpret_cast<float*>(smem);                       // [3][32][32] (f32 chain)
   unsigned char* adjq = smem;                                         // bf16 planes (split chain)
   float* xb = reinterpret_cast<float*>(smem + ADJ_BYTES);             // [CB][XP] (+ 8 floats of slack when BCH)
@@ -150,6 +163,12 @@ __global__ void __launch_bounds__(NW * 64, 2) gcn_chain_kernel(const ChainArgs a
   const int S1 = 3 * a.ncb;                            // aggregated stages, then a.ncb2 plain stages
   const int S = S1 + a.ncb2;
   const int nchunks = a.ncb + a.ncb2;                  // staged source chunks: x blocks, then in2 blocks
+  float rs_s = 1.f, rs_inv = 1.f;                      // f16x3 range scale of the staged sources
+  if constexpr (F16) {
+    float mx = a.in_absmax ? *a.in_absmax : 0.f;
+    if (a.in2_absmax) mx = fmaxf(mx, *a.in2_absmax);
+    f16_range_scale_of<8>(mx, rs_s, rs_inv);
+  }
 
   // bias of this row block, beyond everything the epilogue tile overwrites
   float* bias_s = reinterpret_cast<float*>(smem + a.off_bias);
@@ -179,12 +198,13 @@ __global__ void __launch_bounds__(NW * 64, 2) gcn_chain_kernel(const ChainArgs a
         const float tv = adjn[gi];
         v[q] = ok ? tv : 0.f;
       }
-      unsigned p0, p1, p2;
-      split_pair(v[0], v[1], p0, p1, p2);
+      unsigned p0, p1, p2 = 0;
+      if constexpr (F16) split_pair_f16(v[0], v[1], p0, p1);
+      else split_pair(v[0], v[1], p0, p1, p2);
       const int o = (((ks * 2 + hh) * 32) + col) * 16 + e2 * 4;     // within one (i, plane) image of 2048 bytes
-      *reinterpret_cast<unsigned*>(adjq + (i * 3 + 0) * 2048 + o) = p0;
-      *reinterpret_cast<unsigned*>(adjq + (i * 3 + 1) * 2048 + o) = p1;
-      *reinterpret_cast<unsigned*>(adjq + (i * 3 + 2) * 2048 + o) = p2;
+      *reinterpret_cast<unsigned*>(adjq + (i * PL + 0) * 2048 + o) = p0;
+      *reinterpret_cast<unsigned*>(adjq + (i * PL + 1) * 2048 + o) = p1;
+      if constexpr (!F16) *reinterpret_cast<unsigned*>(adjq + (i * PL + 2) * 2048 + o) = p2;
     }
     if (tid < 8) xb[CB * XP + tid] = 0.f;                            // slack behind the last chunk row
   }
@@ -252,7 +272,38 @@ __global__ void __launch_bounds__(NW * 64, 2) gcn_chain_kernel(const ChainArgs a
   __syncthreads();
 
   float xo[BCH ? 1 : VS];
-  bf16x8 xq[2][3];                                     // split chain: this lane's x fragments (ks, plane)
+  bf16x8 xq[2][PL];                                    // split chain: this lane's x fragments (ks, plane)
+  // one 16-deep step on the split operands, smallest products first (npl == 1, AGCN_GEMM=bf16: the hi*hi product only)
+  auto mfma_step = [&](const bf16x8 (&x)[PL], const bf16x8 (&y)[PL], f32x16 c) __attribute__((always_inline)) {
+    if constexpr (F16) {
+      c = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, x[1]), __builtin_bit_cast(f16x8, y[0]), c, 0, 0, 0);
+      c = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, x[0]), __builtin_bit_cast(f16x8, y[1]), c, 0, 0, 0);
+      c = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, x[0]), __builtin_bit_cast(f16x8, y[0]), c, 0, 0, 0);
+    } else {
+      if (a.npl == 3) {
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x[2], y[0], c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x[0], y[2], c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x[1], y[1], c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x[1], y[0], c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x[0], y[1], c, 0, 0, 0);
+      }
+      c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x[0], y[0], c, 0, 0, 0);
+    }
+    return c;
+  };
+  // 8 consecutive fp32 values -> the PL planes of one fragment (range-scaled when F16)
+  auto split8 = [&](const float (&v)[8], bf16x8 (&q)[PL], float sc) __attribute__((always_inline)) {
+    u32x4 w[3];
+#pragma unroll
+    for (int e2 = 0; e2 < 4; ++e2) {
+      unsigned p0, p1, p2 = 0;
+      if constexpr (F16) split_pair_f16(v[2 * e2] * sc, v[2 * e2 + 1] * sc, p0, p1);
+      else split_pair(v[2 * e2], v[2 * e2 + 1], p0, p1, p2);
+      w[0][e2] = p0; w[1][e2] = p1; w[2][e2] = p2;
+    }
+#pragma unroll
+    for (int pl = 0; pl < PL; ++pl) q[pl] = __builtin_bit_cast(bf16x8, w[pl]);
+  };
   long long tk0 = 0, tk_stage = 0, tk_mat = 0, tk_bar = 0;   // AGCN_GC_DBG & 8: cycles of wave 0 per section
   const long long tk_begin = (a.dbg & 8) ? clock64() : 0;
   for (int s = 0; s < S; ++s) {
@@ -267,6 +318,10 @@ __global__ void __launch_bounds__(NW * 64, 2) gcn_chain_kernel(const ChainArgs a
       const float* xr = xb + wave * V + min(lr, V - 1);
 #pragma unroll
       for (int j = 0; j < 16; ++j) d[j] = xr[((j & 3) + 8 * (j >> 2) + 4 * h) * XP];
+      if constexpr (F16) {
+#pragma unroll
+        for (int j = 0; j < 16; ++j) d[j] *= rs_s;
+      }
       __syncthreads();
       if (chunk + 1 < nchunks) commit_X(chunk + 1);
       if (s + 1 < S) commit_A(s + 1);
@@ -303,82 +358,55 @@ __global__ void __launch_bounds__(NW * 64, 2) gcn_chain_kernel(const ChainArgs a
             // meet the zero rows of the adjacency
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) {
-              u32x4 qh, qm, ql;
+              float xv[8];
 #pragma unroll
-              for (int e2 = 0; e2 < 4; ++e2) {
-                unsigned p0, p1, p2;
-                split_pair(xr[16 * ks + 8 * h + 2 * e2], xr[16 * ks + 8 * h + 2 * e2 + 1], p0, p1, p2);
-                qh[e2] = p0; qm[e2] = p1; ql[e2] = p2;
-              }
-              xq[ks][0] = __builtin_bit_cast(bf16x8, qh);
-              xq[ks][1] = __builtin_bit_cast(bf16x8, qm);
-              xq[ks][2] = __builtin_bit_cast(bf16x8, ql);
+              for (int e = 0; e < 8; ++e) xv[e] = xr[16 * ks + 8 * h + e];
+              split8(xv, xq[ks], rs_s);
             }
           }
-          const unsigned char* aq = adjq + i * 3 * 2048 + (h * 32 + lr) * 16;
+          const unsigned char* aq = adjq + i * PL * 2048 + (h * 32 + lr) * 16;
 #pragma unroll
           for (int ks = 0; ks < 2; ++ks) {
-            const bf16x8 b0 = *reinterpret_cast<const bf16x8*>(aq + 0 * 2048 + ks * 1024);
-            const bf16x8 b1 = *reinterpret_cast<const bf16x8*>(aq + 1 * 2048 + ks * 1024);
-            const bf16x8 b2 = *reinterpret_cast<const bf16x8*>(aq + 2 * 2048 + ks * 1024);
-            if (a.npl == 3) {
-              d = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xq[ks][2], b0, d, 0, 0, 0);
-              d = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xq[ks][0], b2, d, 0, 0, 0);
-              d = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xq[ks][1], b1, d, 0, 0, 0);
-              d = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xq[ks][1], b0, d, 0, 0, 0);
-              d = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xq[ks][0], b1, d, 0, 0, 0);
-            }
-            d = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xq[ks][0], b0, d, 0, 0, 0);
+            bf16x8 bq[PL];
+#pragma unroll
+            for (int pl = 0; pl < PL; ++pl) bq[pl] = *reinterpret_cast<const bf16x8*>(aq + pl * 2048 + ks * 1024);
+            d = mfma_step(xq[ks], bq, d);
           }
         }
       }
       // ---- 2. split G in registers and project: acc[tm] += W_i[:, cb] . G ----
       const unsigned char* ab = abuf + (s & 1) * A_IMG + lane * 16;
-      bf16x8 gb[2][3];
+      bf16x8 gb[2][PL];                                 // (G carries the range scale already)
 #pragma unroll
       for (int hf = 0; hf < 2; ++hf) {
-        u32x4 gh, gm, gl;
+        float gv[8];
 #pragma unroll
-        for (int e2 = 0; e2 < 4; ++e2) {
-          unsigned p0, p1, p2;
-          split_pair(d[8 * hf + 2 * e2], d[8 * hf + 2 * e2 + 1], p0, p1, p2);
-          gh[e2] = p0; gm[e2] = p1; gl[e2] = p2;
-        }
-        gb[hf][0] = __builtin_bit_cast(bf16x8, gh);
-        gb[hf][1] = __builtin_bit_cast(bf16x8, gm);
-        gb[hf][2] = __builtin_bit_cast(bf16x8, gl);
+        for (int e = 0; e < 8; ++e) gv[e] = d[8 * hf + e];
+        split8(gv, gb[hf], 1.f);
       }
       // 2*TM steps of 6 MFMAs; the weight fragments of step k+1 are read while step k runs (order pinned below: the
       // scheduler otherwise sinks every read to its use and waits for it)
-      auto load_w = [&](bf16x8 (&af)[3], int step) __attribute__((always_inline)) {
+      auto load_w = [&](bf16x8 (&af)[PL], int step) __attribute__((always_inline)) {
         const int hf = step / TM, tm = step - hf * TM;
 #pragma unroll
-        for (int pl = 0; pl < 3; ++pl)
+        for (int pl = 0; pl < PL; ++pl)
           af[pl] = *reinterpret_cast<const bf16x8*>(ab + ((pl * 2 + hf) * TM + tm) * 1024);
       };
-      bf16x8 afc[3];
+      bf16x8 afc[PL];
       load_w(afc, 0);
-      __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);
+      __builtin_amdgcn_sched_group_barrier(0x100, PL, 0);
 #pragma unroll
       for (int step = 0; step < 2 * TM; ++step) {
         const int hf = step / TM, tm = step - hf * TM;
-        bf16x8 afn[3];
+        bf16x8 afn[PL];
         if (step + 1 < 2 * TM) load_w(afn, step + 1);
-        // smallest products first; npl == 1 (AGCN_GEMM=bf16): the hi*hi product only
-        if (a.npl == 3) {
-          acc[tm] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afc[2], gb[hf][0], acc[tm], 0, 0, 0);
-          acc[tm] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afc[0], gb[hf][2], acc[tm], 0, 0, 0);
-          acc[tm] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afc[1], gb[hf][1], acc[tm], 0, 0, 0);
-          acc[tm] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afc[1], gb[hf][0], acc[tm], 0, 0, 0);
-          acc[tm] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afc[0], gb[hf][1], acc[tm], 0, 0, 0);
-        }
-        acc[tm] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afc[0], gb[hf][0], acc[tm], 0, 0, 0);
+        acc[tm] = mfma_step(afc, gb[hf], acc[tm]);
         if (step + 1 < 2 * TM) {
-          __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);
+          __builtin_amdgcn_sched_group_barrier(0x100, PL, 0);
 #pragma unroll
-          for (int pl = 0; pl < 3; ++pl) afc[pl] = afn[pl];
+          for (int pl = 0; pl < PL; ++pl) afc[pl] = afn[pl];
         }
-        __builtin_amdgcn_sched_group_barrier(0x008, 6, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, NPROD, 0);
       }
     }
     if (a.dbg & 8) { const long long t = clock64(); tk_mat += t - tk0; tk0 = t; }
@@ -422,7 +450,8 @@ __global__ void __launch_bounds__(NW * 64, 2) gcn_chain_kernel(const ChainArgs a
 #pragma unroll
     for (int tm = 0; tm < TM; ++tm)
 #pragma unroll
-      for (int j = 0; j < 16; ++j) tile[(tm * 32 + mfma_row(j, h)) * TP + wave * V + lr] = acc[tm][j];
+      for (int j = 0; j < 16; ++j)
+        tile[(tm * 32 + mfma_row(j, h)) * TP + wave * V + lr] = F16 ? acc[tm][j] * rs_inv : acc[tm][j];
   }
   __syncthreads();
   if (a.stats) {
@@ -489,16 +518,16 @@ struct ChainGeom {
 };
 
 template <int TM, int NW>
-ChainGeom chain_geometry(int V, int T, int M, int K, bool bch = false) {
+ChainGeom chain_geometry(int V, int T, int M, int K, bool bch = false, int planes = 3) {
   constexpr int BM = TM * 32, FT = NW;
   ChainGeom g;
   g.ntiles = (T + FT - 1) / FT;
   g.ncb = (K + CB - 1) / CB;
   g.nmb = (M + BM - 1) / BM;
   g.XP = (FT * V) | 1;
-  const size_t a_img = (size_t)3 * 2 * TM * 1024;
+  const size_t a_img = (size_t)planes * 2 * TM * 1024;
   const size_t xb_bytes = ((size_t)CB * g.XP * 4 + (bch ? 32 : 0) + 15) & ~(size_t)15;
-  g.smem_bytes = (bch ? (size_t)3 * 3 * 2 * 2 * 32 * 16 : (size_t)3 * 32 * 32 * 4) + xb_bytes + 2 * a_img;
+  g.smem_bytes = (bch ? (size_t)3 * planes * 2 * 2 * 32 * 16 : (size_t)3 * 32 * 32 * 4) + xb_bytes + 2 * a_img;
   const size_t epi_bytes = (size_t)BM * ((FT * V) | 1) * 4 + (size_t)NW * 64 * 2 * 4;
   if (epi_bytes > g.smem_bytes) g.smem_bytes = epi_bytes;
   g.smem_bytes = (g.smem_bytes + 15) & ~(size_t)15;
@@ -513,22 +542,38 @@ struct ChainW2 {
   long sa_m, sa_c;      // W2[m][k] = w[m*sa_m + k*sa_c]
 };
 
-template <int TM, int VS, int NW>
+template <int TM, int VS, int NW, bool F16 = false>
 int chain_launch(ChainArgs a, const float* w, long sa_m, long sa_i, long sa_c, const ChainW2& g_w2, void* ws,
                  size_t ws_bytes, hipStream_t stream) {
-  const ChainGeom g = chain_geometry<TM, NW>(a.V, a.T, a.M, a.K, VS == 0);
+  constexpr int PL = F16 ? 2 : 3;
+  const ChainGeom g = chain_geometry<TM, NW>(a.V, a.T, a.M, a.K, VS == 0, PL);
   if (g.smem_bytes > 160 * 1024) return AGCN_ERR_UNSUPPORTED;
   a.ncb2 = a.in2 ? (a.K2 + CB - 1) / CB : 0;
   const int s_total = 3 * g.ncb + a.ncb2;
-  const size_t a_img = (size_t)3 * 2 * TM * 1024;
-  if ((size_t)g.nmb * s_total * a_img > ws_bytes) return AGCN_ERR_WORKSPACE;
+  const size_t a_img = (size_t)PL * 2 * TM * 1024;
+  const size_t img_bytes = (size_t)g.nmb * s_total * a_img;
+  if (img_bytes + (F16 ? 16 : 0) > ws_bytes) return AGCN_ERR_WORKSPACE;
+  if constexpr (F16) {
+    // maxima the caller did not supply: one streaming pass each, into the 16 bytes behind the weight images (the
+    // workspace is sized for three planes, the f16x3 images take two)
+    unsigned* amax = reinterpret_cast<unsigned*>(static_cast<char*>(ws) + img_bytes);
+    if (!a.in_absmax) {
+      if (int rc = agcn_launch_absmax(a.in, (long)a.N * a.K * a.T * a.V, amax, stream)) return rc;
+      a.in_absmax = reinterpret_cast<const float*>(amax);
+    }
+    if (a.in2 && !a.in2_absmax) {
+      if (int rc = agcn_launch_absmax(a.in2, (long)a.N * a.K2 * a.T * a.V, amax + 1, stream)) return rc;
+      a.in2_absmax = reinterpret_cast<const float*>(amax + 1);
+    }
+    if (!a.in2) a.in2_absmax = nullptr;
+  }
   a.ntiles = g.ntiles; a.ncb = g.ncb; a.nmb = g.nmb; a.XP = g.XP; a.off_bias = g.off_bias;
   a.wp = (const unsigned short*)ws;
   ChainPackArgs pk;
   pk.w = w; pk.wp = (unsigned short*)ws; pk.M = a.M; pk.K = a.K; pk.ncb = g.ncb;
   pk.sa_m = sa_m; pk.sa_i = sa_i; pk.sa_c = sa_c;
   pk.nsub = 3; pk.s_total = s_total; pk.s_off = 0;
-  hipLaunchKernelGGL((chain_pack_kernel<TM>), dim3(g.nmb * g.ncb * 3), dim3(256), 0, stream, pk);
+  hipLaunchKernelGGL((chain_pack_kernel<TM, F16>), dim3(g.nmb * g.ncb * 3), dim3(256), 0, stream, pk);
   int rc = agcn_check_launch();
   if (rc) return rc;
   if (a.ncb2 > 0) {        // images of the plain stages, after the aggregated ones of each row block
@@ -536,14 +581,15 @@ int chain_launch(ChainArgs a, const float* w, long sa_m, long sa_i, long sa_c, c
     p2.w = g_w2.w; p2.wp = (unsigned short*)ws; p2.M = a.M; p2.K = a.K2; p2.ncb = a.ncb2;
     p2.sa_m = g_w2.sa_m; p2.sa_i = 0; p2.sa_c = g_w2.sa_c;
     p2.nsub = 1; p2.s_total = s_total; p2.s_off = 3 * g.ncb;
-    hipLaunchKernelGGL((chain_pack_kernel<TM>), dim3(g.nmb * a.ncb2), dim3(256), 0, stream, p2);
+    hipLaunchKernelGGL((chain_pack_kernel<TM, F16>), dim3(g.nmb * a.ncb2), dim3(256), 0, stream, p2);
     rc = agcn_check_launch();
     if (rc) return rc;
   }
-  auto kern = gcn_chain_kernel<TM, VS, NW>;
+  auto kern = gcn_chain_kernel<TM, VS, NW, F16>;
   static unsigned char lds_ok[AGCN_MAX_DEVICES] = {};   // per (kernel instantiation, device): the attribute is per device
   if (int e = agcn_allow_big_lds_rt(reinterpret_cast<const void*>(kern), lds_ok)) return e;
   hipLaunchKernelGGL(kern, dim3((unsigned)(a.N * g.ntiles * g.nmb)), dim3(NW * 64), g.smem_bytes, stream, a);
+  AGCN_NOTE_KERNEL("gcn_chain_kernel<%d, %d, %d, %s>", TM, VS, NW, F16 ? "true" : "false");
   return agcn_check_launch();
 }
 
@@ -553,6 +599,8 @@ int chain_dispatch_vs(const ChainArgs& a, const float* w, long sa_m, long sa_i, 
   // split-bf16 aggregation unless AGCN_CHAIN_F32=1 (exact-f32 MFMA chain, VS = ceil(V/2) steps) or AGCN_GEMM=bf16
   // (one product: keep the aggregation exact)
   static const int f32chain = getenv("AGCN_CHAIN_F32") ? atoi(getenv("AGCN_CHAIN_F32")) : 0;
+  if (!f32chain && a.npl == 3 && agcn_chain_f16x3())
+    return chain_launch<TM, 0, NW, true>(a, w, sa_m, sa_i, sa_c, w2, ws, ws_bytes, stream);
   if (!f32chain && a.npl == 3) return chain_launch<TM, 0, NW>(a, w, sa_m, sa_i, sa_c, w2, ws, ws_bytes, stream);
   const int vs = (a.V + 1) / 2;
   if (vs == 13) return chain_launch<TM, 13, NW>(a, w, sa_m, sa_i, sa_c, w2, ws, ws_bytes, stream);
@@ -838,6 +886,12 @@ static inline int chain_waves() {
     nw = (e && atoi(e) == 8) ? 8 : 4;
   }
   return nw;
+}
+
+// 1 (default): aggregate+project forward / backward-data on f16x3 in the fp32-equivalent mode; AGCN_CHAIN_F16X3=0: bf16x6
+int agcn_chain_f16x3() {
+  static const int on = getenv("AGCN_CHAIN_F16X3") ? atoi(getenv("AGCN_CHAIN_F16X3")) : 1;
+  return on && agcn_npl() == 3;
 }
 
 bool agcn_gcn_chain_supported(int M, int K, int V) { return M >= 1 && K >= 1 && V <= 32; }

@@ -1,0 +1,72 @@
+// "f16x3" split arithmetic shared by the temporal-convolution and graph-convolution kernels: two fp16 pieces per
+// operand, x = h1 + h2 (11 + 11 significand bits), and the three products h1*h1 + h1*h2 + h2*h1 on
+// v_mfma_f32_32x32x16_f16: dropped terms below 2^-22 |a*b|.  Emulated on the CPU against fp64
+// (tools/split_numerics.py): 9e-7 of the result scale for O(1) operands, the same as an fp32 GEMM's own rounding (7e-7);
+// half the matrix work, half the split arithmetic and two thirds of the LDS bytes of bf16x6.
+#pragma once
+#include "agcn_common.h"
+
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+typedef float sf_f32x2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ void split_pair_f16(float a, float b, unsigned& p1, unsigned& p2) {
+  const sf_f32x2 v = {a, b};
+  const f16x2 h = __builtin_convertvector(v, f16x2);            // v_cvt_pk_f16_f32 (round to nearest even)
+  const sf_f32x2 r = v - __builtin_convertvector(h, sf_f32x2);
+  p1 = __builtin_bit_cast(unsigned, h);
+  p2 = __builtin_bit_cast(unsigned, __builtin_convertvector(r, f16x2));
+}
+
+// fp16 holds 6e-5 < |x| < 65504 with full precision: the f16x3 kernels multiply the streamed operand by the power of two
+// (exact) that brings the TENSOR's maximum m into [2^TARGET, 2^(TARGET+1)) and undo it on the accumulators (exact).  That
+// covers activations that grew past 2^15 as well as gradients of 1e-6; elements far below the maximum lose bits only
+// below 2^-25 * 2^(14-TARGET) of it, which is what an fp32 accumulation of the same sum loses too.
+// TARGET = 14: the operand itself is split (temporal convolutions).  TARGET = 8: what is split next is the operand times
+// an adjacency (graph chain), whose column sums of |A^| may reach 2^7 before fp16 overflows.
+template <int TARGET = 14>
+__device__ __forceinline__ void f16_range_scale_of(float m, float& s, float& inv) {
+  s = 1.f; inv = 1.f;
+  if (m > 0.f) {
+    int e = (int)((__builtin_bit_cast(unsigned, m) >> 23) & 0xffu) - 127;   // floor(log2 m); inf / nan: 128
+    e = max(e, -100);
+    s = __builtin_bit_cast(float, (unsigned)(127 - (e - TARGET)) << 23);
+    inv = __builtin_bit_cast(float, (unsigned)(127 + (e - TARGET)) << 23);
+  }
+}
+// (s, 1/s) from the device scalar max |x|
+__device__ __forceinline__ void f16_range_scale(const float* absmax, float& s, float& inv) {
+  s = 1.f; inv = 1.f;
+  if (absmax) f16_range_scale_of<14>(*absmax, s, inv);
+}
+
+// max |x| of a tensor -> *out (as the bit pattern of a non-negative float: unsigned order = float order); *out zeroed first
+static __global__ void __launch_bounds__(256) absmax_kernel(const float* __restrict__ x, long n, unsigned* __restrict__ out) {
+  __shared__ unsigned red[4];
+  unsigned m = 0;
+  // 16-byte loads from the first aligned element on; the (up to 3) floats in front of it and the tail go one by one
+  long head = (long)(((16 - (reinterpret_cast<unsigned long>(x) & 15)) & 15) >> 2);
+  if (head > n) head = n;
+  const float* xa = x + head;
+  const long na = n - head, n4 = na >> 2;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
+    const f32x4 v = reinterpret_cast<const f32x4*>(xa)[i];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) m = max(m, __builtin_bit_cast(unsigned, v[k]) & 0x7fffffffu);
+  }
+  for (long i = (n4 << 2) + (long)blockIdx.x * 256 + threadIdx.x; i < na; i += (long)gridDim.x * 256)
+    m = max(m, __builtin_bit_cast(unsigned, xa[i]) & 0x7fffffffu);
+  if (blockIdx.x == 0 && (long)threadIdx.x < head) m = max(m, __builtin_bit_cast(unsigned, x[threadIdx.x]) & 0x7fffffffu);
+#pragma unroll
+  for (int k = 32; k >= 1; k >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, k));
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) atomicMax(out, max(max(red[0], red[1]), max(red[2], red[3])));
+}
+
+// *out = max |x| over n floats, on `stream`
+static inline int agcn_launch_absmax(const float* x, long n, unsigned* out, hipStream_t stream) {
+  if (hipMemsetAsync(out, 0, 4, stream) != hipSuccess) return AGCN_ERR_ARG;
+  hipLaunchKernelGGL(absmax_kernel, dim3(2048), dim3(256), 0, stream, x, n, out);
+  return agcn_check_launch();
+}

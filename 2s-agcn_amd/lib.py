@@ -24,6 +24,7 @@ SIGNATURES = {
     "agcn_arch": (ctypes.c_char_p, []),
     "agcn_last_kernel": (ctypes.c_char_p, []),
     "agcn_gemm_mode": (ctypes.c_char_p, []),
+    "agcn_chain_mode": (ctypes.c_char_p, []),
     "agcn_conv_tile_frames": (_I, [_I, _I]),
     "agcn_conv_num_tiles": (_I, [_I, _I]),
     "agcn_conv_stats_tiles": (_I, [_I, _I, _I, _I, _I, _I]),

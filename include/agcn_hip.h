@@ -44,6 +44,9 @@ const char* agcn_arch(void);     /* "gfx950" */
  * "f32" = exact-f32 MFMA, "bf16x3"), read once per process from the environment variable AGCN_GEMM */
 const char* agcn_last_kernel(void);
 const char* agcn_gemm_mode(void);
+/* arithmetic of the aggregate+project chain: "f16x3" (two fp16 pieces per operand, three products, operands range-scaled
+ * by the tensor maximum) in the default mode, "bf16x6" with AGCN_CHAIN_F16X3=0, else agcn_gemm_mode() */
+const char* agcn_chain_mode(void);
 
 /* ---- tile geometry queries (sizes of the partial slabs below) ---------------------------------------------------- */
 int agcn_conv_tile_frames(int V, int T_out);     /* frames per position tile of the contraction kernels (256/V) */
