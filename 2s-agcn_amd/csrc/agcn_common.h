@@ -81,7 +81,8 @@ size_t agcn_gcn_chain_workspace(int M, int K, int K2, int T, int V);
 int agcn_gcn_chain(int mode, const float* in, const float* adj, const float* wcat, const float* bias, float* out,
                    float* stats_part, int accumulate, const float* add1, const float* mask1, const float* add2,
                    const float* mask2, int mask_bits, const float* in2, const float* w2, int K2, void* ws, size_t ws_bytes,
-                   int N, int C, int Cout, int T, int V, hipStream_t stream, int relu = 0, int w2_rows_are_outputs = 0);
+                   int N, int C, int Cout, int T, int V, hipStream_t stream, int relu = 0, int w2_rows_are_outputs = 0,
+                   const float* in_absmax = nullptr, const float* in2_absmax = nullptr);
 
 bool agcn_gcn_dadj_chain_supported(int C, int V);
 int agcn_gcn_dadj_chain_slots(int C, int T);

@@ -727,15 +727,26 @@ int agcn_conv_bwd_data_ex(const float* dy, const float* w, float* dx, int accumu
 }
 
 // y[n][o][t,v] = bias[o] + sum_i sum_c wcat[o][i*C+c] * sum_u x[n][c][t,u] adj[n][i][u][v]
+int agcn_gcn_aggregate_project_fwd_ex(const float* x, const float* adj, const float* wcat, const float* bias, float* y,
+                                      float* stats_part, void* workspace, size_t workspace_bytes, int N, int C, int Cout,
+                                      int T, int V, const float* x_absmax, void* stream);
 int agcn_gcn_aggregate_project_fwd(const float* x, const float* adj, const float* wcat, const float* bias, float* y,
                                    float* stats_part, void* workspace, size_t workspace_bytes, int N, int C, int Cout,
                                    int T, int V, void* stream) {
+  return agcn_gcn_aggregate_project_fwd_ex(x, adj, wcat, bias, y, stats_part, workspace, workspace_bytes, N, C, Cout, T, V,
+                                           nullptr, stream);
+}
+// x_absmax: device scalar max |x| left behind by the kernel that produced x (agcn_bn_act_fwd_ex), for the range scale
+// of the f16x3 chain; null: the chain takes it with a streaming pass of its own
+int agcn_gcn_aggregate_project_fwd_ex(const float* x, const float* adj, const float* wcat, const float* bias, float* y,
+                                      float* stats_part, void* workspace, size_t workspace_bytes, int N, int C, int Cout,
+                                      int T, int V, const float* x_absmax, void* stream) {
   if (!x || !adj || !wcat || !y || !workspace || N <= 0 || C <= 0 || Cout <= 0 || T <= 0 || V <= 0 || V > 32)
     return AGCN_ERR_ARG;
   // (the 3-channel first layer's forward stays on the f32 kernel: measured 193 us against 260 us chained)
   if (agcn_chained() && C >= 32 && agcn_gcn_chain_supported(Cout, C, V))
     return agcn_gcn_chain(0, x, adj, wcat, bias, y, stats_part, 0, nullptr, nullptr, nullptr, nullptr, 0, nullptr, nullptr,
-                          0, workspace, workspace_bytes, N, C, Cout, T, V, (hipStream_t)stream);
+                          0, workspace, workspace_bytes, N, C, Cout, T, V, (hipStream_t)stream, 0, 0, x_absmax, nullptr);
   Problem p = {};
   ConvGemmArgs& a = p.a;
   a.in = x; a.bias = bias; a.out = y; a.adj = adj; a.stats = stats_part;
@@ -780,15 +791,42 @@ int agcn_conv9_infer(const float* x, const float* w, const float* bias, const fl
 }
 
 // dx[n][c][t,u] (+)= sum_i sum_o wcat[o][i*C+c] * sum_v dy[n][o][t,v] adj[n][i][u][v]   (+ masked addends)
+int agcn_gcn_bwd_data_fused_supported(int C, int Cout, int V);
+int agcn_gcn_aggregate_project_bwd_data_ex(const float* dy, const float* adj, const float* wcat, const float* dtp,
+                                           const float* w2, int K2, float* dx, int accumulate, const float* add1,
+                                           const float* mask1, const float* add2, const float* mask2, int mask_bits,
+                                           void* workspace, size_t workspace_bytes, int N, int C, int Cout, int T, int V,
+                                           const float* dy_absmax, const float* dtp_absmax, void* stream);
 int agcn_gcn_aggregate_project_bwd_data(const float* dy, const float* adj, const float* wcat, float* dx,
                                         int accumulate, const float* add1, const float* mask1, const float* add2,
                                         const float* mask2, int mask_bits, void* workspace, size_t workspace_bytes,
                                         int N, int C, int Cout, int T, int V, void* stream) {
+  return agcn_gcn_aggregate_project_bwd_data_ex(dy, adj, wcat, nullptr, nullptr, 0, dx, accumulate, add1, mask1, add2,
+                                                mask2, mask_bits, workspace, workspace_bytes, N, C, Cout, T, V, nullptr,
+                                                nullptr, stream);
+}
+// Both backward-data forms behind one entry point (dtp null: the plain one; else the fused 1x1 term as in
+// agcn_gcn_aggregate_project_bwd_data_fused), with the device scalars max |dy| / max |dtp| their producers left behind
+// (agcn_bn_bwd_apply_ex; null: the f16x3 chain takes them with a streaming pass of its own).
+int agcn_gcn_aggregate_project_bwd_data_ex(const float* dy, const float* adj, const float* wcat, const float* dtp,
+                                           const float* w2, int K2, float* dx, int accumulate, const float* add1,
+                                           const float* mask1, const float* add2, const float* mask2, int mask_bits,
+                                           void* workspace, size_t workspace_bytes, int N, int C, int Cout, int T, int V,
+                                           const float* dy_absmax, const float* dtp_absmax, void* stream) {
   if (!dy || !adj || !wcat || !dx || !workspace || N <= 0 || C <= 0 || Cout <= 0 || T <= 0 || V <= 0 || V > 32)
     return AGCN_ERR_ARG;
+  if (dtp) {
+    if (!w2 || K2 <= 0) return AGCN_ERR_ARG;
+    if (!agcn_gcn_bwd_data_fused_supported(C, Cout, V)) return AGCN_ERR_UNSUPPORTED;
+    if (agcn_gcn_chain_workspace(C, Cout, K2, T, V) > workspace_bytes) return AGCN_ERR_WORKSPACE;
+    return agcn_gcn_chain(1, dy, adj, wcat, nullptr, dx, nullptr, accumulate, add1, mask1, add2, mask2, mask_bits, dtp,
+                          w2, K2, workspace, workspace_bytes, N, C, Cout, T, V, (hipStream_t)stream, 0, 0, dy_absmax,
+                          dtp_absmax);
+  }
   if (agcn_chained() && agcn_gcn_chain_supported(C, Cout, V))
     return agcn_gcn_chain(1, dy, adj, wcat, nullptr, dx, nullptr, accumulate, add1, mask1, add2, mask2, mask_bits,
-                          nullptr, nullptr, 0, workspace, workspace_bytes, N, C, Cout, T, V, (hipStream_t)stream);
+                          nullptr, nullptr, 0, workspace, workspace_bytes, N, C, Cout, T, V, (hipStream_t)stream, 0, 0,
+                          dy_absmax, nullptr);
   Problem p = {};
   ConvGemmArgs& a = p.a;
   a.in = dy; a.out = dx; a.adj = adj; a.accumulate = accumulate;
@@ -811,13 +849,10 @@ int agcn_gcn_aggregate_project_bwd_data_fused(const float* dy, const float* adj,
                                               const float* mask1, const float* add2, const float* mask2, int mask_bits,
                                               void* workspace, size_t workspace_bytes, int N, int C, int Cout, int T,
                                               int V, void* stream) {
-  if (!dy || !adj || !wcat || !dtp || !w2 || !dx || !workspace || N <= 0 || C <= 0 || Cout <= 0 || K2 <= 0 || T <= 0 ||
-      V <= 0 || V > 32)
-    return AGCN_ERR_ARG;
-  if (!agcn_gcn_bwd_data_fused_supported(C, Cout, V)) return AGCN_ERR_UNSUPPORTED;
-  if (agcn_gcn_chain_workspace(C, Cout, K2, T, V) > workspace_bytes) return AGCN_ERR_WORKSPACE;
-  return agcn_gcn_chain(1, dy, adj, wcat, nullptr, dx, nullptr, accumulate, add1, mask1, add2, mask2, mask_bits, dtp, w2,
-                        K2, workspace, workspace_bytes, N, C, Cout, T, V, (hipStream_t)stream);
+  if (!dtp) return AGCN_ERR_ARG;
+  return agcn_gcn_aggregate_project_bwd_data_ex(dy, adj, wcat, dtp, w2, K2, dx, accumulate, add1, mask1, add2, mask2,
+                                                mask_bits, workspace, workspace_bytes, N, C, Cout, T, V, nullptr, nullptr,
+                                                stream);
 }
 
 // dadj_part[n][i][slot][u][v] = sum over the slot's (c,t) of x[n][c][t,u] * (sum_o wcat[o][i*C+c] dy[n][o][t,v])

@@ -910,9 +910,11 @@ size_t agcn_gcn_chain_workspace(int M, int K, int K2, int T, int V) {
 int agcn_gcn_chain(int mode, const float* in, const float* adj, const float* wcat, const float* bias, float* out,
                    float* stats_part, int accumulate, const float* add1, const float* mask1, const float* add2,
                    const float* mask2, int mask_bits, const float* in2, const float* w2, int K2, void* ws, size_t ws_bytes,
-                   int N, int C, int Cout, int T, int V, hipStream_t stream, int relu, int w2_rows_are_outputs) {
+                   int N, int C, int Cout, int T, int V, hipStream_t stream, int relu, int w2_rows_are_outputs,
+                   const float* in_absmax, const float* in2_absmax) {
   ChainArgs a = {};
   a.relu = relu;
+  a.in_absmax = in_absmax; a.in2_absmax = in2_absmax;   // f16x3: maxima the producers left behind (null: a pre-pass)
   a.npl = agcn_npl();
   { static const int dbg = getenv("AGCN_GC_DBG") ? atoi(getenv("AGCN_GC_DBG")) : 0; a.dbg = dbg; }
   // optional fused 1x1 term (backward-data only): out += W2^T . in2 with w2 (K2, M) row-major, e.g. the theta/phi

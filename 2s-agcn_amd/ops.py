@@ -7,6 +7,7 @@ extension never allocates or keeps device memory.  Everything here launches on t
 Maths: SURVEY.md Appendix A (checked against the reference ``agcn.py:92-109`` by the oracle tests).
 """
 import os
+import weakref
 
 import torch
 
@@ -98,6 +99,24 @@ def _side_join():
 def fused_amax_enabled():
     """AGCN_FUSED_AMAX=0: the split-fp16 convolutions compute their operand's maximum in a pass of their own (A/B)."""
     return os.environ.get('AGCN_FUSED_AMAX', '1') != '0'
+
+
+# max |out| of the last unit output a BatchNorm pass produced, for the f16x3 chain of the unit that consumes it:
+# (weak reference to the tensor, its version counter, the device scalar).  Taken only by the very tensor object it
+# describes, unmodified since; anything else makes the chain take the maximum with a pass of its own.
+_OUT_AMAX = [None]
+_OUT_AMAX_STATS = [0, 0]      # [misses, hits] of _take_out_amax (diagnostic)
+
+
+def _note_out_amax(t, amax):
+    _OUT_AMAX[0] = (weakref.ref(t), t._version, amax) if amax is not None else None
+
+
+def _take_out_amax(t):
+    e = _OUT_AMAX[0]
+    hit = e is not None and e[0]() is t and t._version == e[1]
+    _OUT_AMAX_STATS[int(hit)] += 1
+    return e[2] if hit else None
 
 
 def conv_out_frames(T, taps, stride):
@@ -215,7 +234,7 @@ def gcn_first_fwd(x, adj, wcat, bias, wdown, bdown, want_stats=False):
     return ypre, st, dpre, st2
 
 
-def aggregate_project_fwd(x, adj, wcat, bias, want_stats=False):
+def aggregate_project_fwd(x, adj, wcat, bias, want_stats=False, x_amax=None):
     """y = sum_i Wd_i (x . adj_i) + bias ; wcat: (Cout, 3C) = [Wd_0 | Wd_1 | Wd_2]."""
     N, C, T, V = x.shape
     Cout = wcat.shape[0]
@@ -225,15 +244,15 @@ def aggregate_project_fwd(x, adj, wcat, bias, want_stats=False):
         nt = _L().agcn_gcn_stats_tiles(C, Cout, T, V)
         stats = _empty((N * nt, 2, Cout), x)
     ws, nb = _gcn_ws(C, Cout, T, V, x)
-    _lib.check(_L().agcn_gcn_aggregate_project_fwd(_lib.ptr(x), _lib.ptr(adj), _lib.ptr(wcat), _lib.ptr(bias),
-                                                   _lib.ptr(y), _lib.ptr(stats), ws.data_ptr(), nb, N, C, Cout, T, V,
-                                                   _lib.stream()),
+    _lib.check(_L().agcn_gcn_aggregate_project_fwd_ex(_lib.ptr(x), _lib.ptr(adj), _lib.ptr(wcat), _lib.ptr(bias),
+                                                      _lib.ptr(y), _lib.ptr(stats), ws.data_ptr(), nb, N, C, Cout, T, V,
+                                                      _lib.ptr(x_amax), _lib.stream()),
                "agcn_gcn_aggregate_project_fwd")
     return y, stats
 
 
 def aggregate_project_bwd_data(dy, adj, wcat, x_shape, out=None, accumulate=False, add1=None, mask1=None,
-                               add2=None, mask2=None, dtp=None, wab=None):
+                               add2=None, mask2=None, dtp=None, wab=None, dy_amax=None, dtp_amax=None):
     """dx (+)= sum_i Wd_i^T (dy . adj_i^T) + add1*[mask1] + add2*[mask2] [+ wab^T dtp].  The masks are fp32 tensors
     (> 0 passes) or, both of them, int32 sign bit masks (bn_act_fwd(..., want_bits=True)).  dtp/wab: the 1x1 term of
     the adaptive branch fused into the same pass (only where fused_bwd_data_supported says so)."""
@@ -248,15 +267,15 @@ def aggregate_project_bwd_data(dy, adj, wcat, x_shape, out=None, accumulate=Fals
     mp = _lib.ptr_bits if mbits else _lib.ptr
     if dtp is not None:
         K2 = dtp.shape[1]
-        _lib.check(_L().agcn_gcn_aggregate_project_bwd_data_fused(
+        _lib.check(_L().agcn_gcn_aggregate_project_bwd_data_ex(
             _lib.ptr(dy), _lib.ptr(adj), _lib.ptr(wcat), _lib.ptr(dtp), _lib.ptr(wab.reshape(K2, C)), K2, _lib.ptr(dx),
             int(accumulate), _lib.ptr(add1), mp(mask1), _lib.ptr(add2), mp(mask2), mbits, ws.data_ptr(), nb, N, C, Cout,
-            T, V, _lib.stream()), "agcn_gcn_aggregate_project_bwd_data_fused")
+            T, V, _lib.ptr(dy_amax), _lib.ptr(dtp_amax), _lib.stream()), "agcn_gcn_aggregate_project_bwd_data_fused")
         return dx
-    _lib.check(_L().agcn_gcn_aggregate_project_bwd_data(
-        _lib.ptr(dy), _lib.ptr(adj), _lib.ptr(wcat), _lib.ptr(dx), int(accumulate), _lib.ptr(add1), mp(mask1),
-        _lib.ptr(add2), mp(mask2), mbits, ws.data_ptr(), nb, N, C, Cout, T, V, _lib.stream()),
-        "agcn_gcn_aggregate_project_bwd_data")
+    _lib.check(_L().agcn_gcn_aggregate_project_bwd_data_ex(
+        _lib.ptr(dy), _lib.ptr(adj), _lib.ptr(wcat), None, None, 0, _lib.ptr(dx), int(accumulate), _lib.ptr(add1),
+        mp(mask1), _lib.ptr(add2), mp(mask2), mbits, ws.data_ptr(), nb, N, C, Cout, T, V, _lib.ptr(dy_amax), None,
+        _lib.stream()), "agcn_gcn_aggregate_project_bwd_data")
     return dx
 
 
@@ -635,7 +654,7 @@ def gcn_forward(c, x, A, PA, wab, bab, wd, bd, bn, down, training, alpha=None, a
         # 3-channel first layer: aggregate+project and the `down` convolution in one pass over x (csrc/gcn_first.hip)
         ypre, st, dpre, st2 = gcn_first_fwd(x, adj, wd, bd, down[0], down[1], want_stats=training)
     else:
-        ypre, st = aggregate_project_fwd(x, adj, wd, bd, want_stats=training)
+        ypre, st = aggregate_project_fwd(x, adj, wd, bd, want_stats=training, x_amax=_take_out_amax(x))
     bn2 = None
     if not first:
         dpre = None
@@ -665,8 +684,9 @@ def gcn_backward(c, dout, extra_add=None, extra_mask=None):
     x, tp, P, adj, ypre, dpre, out = c.g_x, c.g_tp, c.g_P, c.g_adj, c.g_ypre, c.g_dpre, c.g_out
     wab, wd, gamma1, wdown, gamma2 = c.g_params
     Cout = wd.shape[0]
+    dy_amax = _empty((1,), dout) if fused_amax_enabled() else None   # max |dypre| for the f16x3 backward-data chain
     dypre, dg1, db1, ddpre, dg2, db2 = bn_bwd(dout, c.g_bits, ypre, gamma1, c.g_bn1, dpre, gamma2, c.g_bn2,
-                                              sync=c.g_sync, gcount=c.g_count)
+                                              sync=c.g_sync, gcount=c.g_count, amax_out=dy_amax)
     dwd = _side_run(lambda: project_bwd_weight(dypre, x, adj, Cout), (dypre, x, adj))
     dPA = dwab = dbab = dalpha = dtp = None
     if c.g_adaptive:      # adjacency branch first: its dtp rides along in the dx kernel where that is supported
@@ -674,6 +694,7 @@ def gcn_backward(c, dout, extra_add=None, extra_mask=None):
         dwab = _side_run(lambda: conv_bwd_weight(dtp, x, wab.shape), (dtp, x))
     fuse = dtp is not None and fused_bwd_data_supported(x.shape[1], Cout, x.shape[3])
     ftp = dict(dtp=dtp, wab=wab) if fuse else {}
+    ftp['dy_amax'] = dy_amax
     if dpre is None:      # identity `down`: dx += dout * (out > 0)
         dx = aggregate_project_bwd_data(dypre, adj, wd, x.shape, add1=dout, mask1=c.g_bits, add2=extra_add,
                                         mask2=extra_mask, **ftp)
@@ -702,11 +723,15 @@ def tcn_forward(c, g, w, b, bn, stride, res_x, res, relu, training, sync=None):
     rpre = bn2 = None
     if res is None or isinstance(res, str):
         (bn1,), gcount = _bn_coeffs(training, [st], count, [bn], sync, N)
-        out, bits = bn_act_fwd(zpre, bn1, None if res is None else res_x, None, relu=relu, want_bits=True)
+        o_amax = _empty((1,), g) if fused_amax_enabled() else None   # max |out| for the next unit's f16x3 chain
+        out, bits = bn_act_fwd(zpre, bn1, None if res is None else res_x, None, relu=relu, want_bits=True,
+                               amax_out=o_amax)
     else:
         rpre, st2 = conv_fwd(res_x, res[0], res[1], stride, want_stats=training)
         (bn1, bn2), gcount = _bn_coeffs(training, [st, st2], count, [bn, res[2:]], sync, N)
-        out, bits = bn_act_fwd(zpre, bn1, rpre, bn2, relu=relu, want_bits=True)
+        o_amax = _empty((1,), g) if fused_amax_enabled() else None
+        out, bits = bn_act_fwd(zpre, bn1, rpre, bn2, relu=relu, want_bits=True, amax_out=o_amax)
+    _note_out_amax(out, o_amax)
     c.t_sync, c.t_count = sync, gcount
     c.t_bits = bits
     c.t_g, c.t_zpre, c.t_rpre, c.t_out, c.t_bn1, c.t_bn2 = g, zpre, rpre, out, bn1, bn2

@@ -94,6 +94,17 @@ int agcn_bn_bwd_apply_ex(const float* part, int nrows, double count, float param
                          const float* invstd1, const float* y2, const float* gamma2, const float* mean2,
                          const float* invstd2, float* coef, float* dy1, float* dgamma1, float* dbeta1, float* dy2,
                          float* dgamma2, float* dbeta2, float* absmax1_out, int N, int C, int P, void* stream);
+/* the aggregate+project chain runs on f16x3 too (agcn_chain_mode): x_absmax = max |x| (agcn_bn_act_fwd_ex of the previous
+ * unit), dy_absmax = max |dy| (agcn_bn_bwd_apply_ex), dtp_absmax = max |dtp|; any of them NULL: a streaming pass inside.
+ * agcn_gcn_aggregate_project_bwd_data_ex covers both backward-data forms: dtp NULL = the plain one, else the fused one. */
+int agcn_gcn_aggregate_project_fwd_ex(const float* x, const float* adj, const float* wcat, const float* bias, float* y,
+                                      float* stats_part, void* workspace, size_t workspace_bytes, int N, int C, int Cout,
+                                      int T, int V, const float* x_absmax, void* stream);
+int agcn_gcn_aggregate_project_bwd_data_ex(const float* dy, const float* adj, const float* wcat, const float* dtp,
+                                           const float* w2, int K2, float* dx, int accumulate, const float* add1,
+                                           const float* mask1, const float* add2, const float* mask2, int mask_bits,
+                                           void* workspace, size_t workspace_bytes, int N, int C, int Cout, int T, int V,
+                                           const float* dy_absmax, const float* dtp_absmax, void* stream);
 int agcn_conv_fwd_ex(const float* x, const float* w, const float* bias, float* y, float* stats_part, void* workspace,
                      size_t workspace_bytes, int N, int Cin, int Cout, int T, int V, int taps, int stride,
                      const float* x_absmax, void* stream);
