@@ -624,6 +624,7 @@ struct DadjArgs {
   int N, C, Cout, T, V;
   int ntiles, nkc, nmb, nslots, gpc;   // gpc = row blocks per subset (C / BM)
   int npl;                     // 3: six split products (bf16x6) ; 1: hi*hi only (bf16)
+  const float* dy_absmax;      // f16x3: device scalar max |dy| for the range scale
 };
 
 struct DadjPackArgs {
@@ -635,12 +636,13 @@ struct DadjPackArgs {
 constexpr int KC = 32;         // dy channels per stage (two 16-deep MFMA steps)
 
 // one block per (mblock, kchunk) image: [plane][ks][tm][lane][8]; slot e of lane (row m, h) = channel kc*32 + ks*16 + h*8 + e
-template <int TM>
+template <int TM, bool F16>
 __global__ void __launch_bounds__(256) dadj_pack_kernel(const DadjPackArgs p) {
   constexpr int BM = TM * 32;
+  constexpr int PL = F16 ? 2 : 3;
   constexpr int PER_PLANE = 2 * TM * 64 * 8;
   const int kc = blockIdx.x % p.nkc, mb = blockIdx.x / p.nkc;
-  unsigned short* dst = p.wp + (long)blockIdx.x * 3 * PER_PLANE;
+  unsigned short* dst = p.wp + (long)blockIdx.x * PL * PER_PLANE;
   for (int e = threadIdx.x; e < PER_PLANE / 2; e += 256) {
     const int e2 = e & 3;
     const int lane = (e >> 2) & 63;
@@ -654,26 +656,32 @@ __global__ void __launch_bounds__(256) dadj_pack_kernel(const DadjPackArgs p) {
       const int o = kc * KC + ks * 16 + h * 8 + 2 * e2 + q;
       v[q] = (m < p.C3 && o < p.Cout) ? p.w[(long)o * p.C3 + m] : 0.f;
     }
-    unsigned ph, pm, pl;
-    split_pair(v[0], v[1], ph, pm, pl);
+    unsigned ph, pm, pl = 0;
+    if constexpr (F16) split_pair_f16(v[0], v[1], ph, pm);
+    else split_pair(v[0], v[1], ph, pm, pl);
     const int o2 = ((ks * TM + tm) * 64 + lane) * 8 + 2 * e2;
     *reinterpret_cast<unsigned*>(dst + 0 * PER_PLANE + o2) = ph;
     *reinterpret_cast<unsigned*>(dst + 1 * PER_PLANE + o2) = pm;
-    *reinterpret_cast<unsigned*>(dst + 2 * PER_PLANE + o2) = pl;
+    if constexpr (!F16) *reinterpret_cast<unsigned*>(dst + 2 * PER_PLANE + o2) = pl;
   }
 }
 
-template <int TM, int NW>
+// F16: the projection H = Wd_i^T dy on f16x3 (split_f16.h): dy is multiplied by the power of two that brings max |dy| into
+// [2^14, 2^15) while it is split, the partial sums by its inverse when they are stored.
+template <int TM, int NW, bool F16 = false>
 __global__ void __launch_bounds__(NW * 64, 2) gcn_dadj_chain_kernel(const DadjArgs a) {
   constexpr int NT = NW * 64, FT = NW, BM = TM * 32;
-  constexpr int A_IMG = 3 * 2 * TM * 1024;             // bytes of one stage's weight image
+  constexpr int PL = F16 ? 2 : 3;
+  constexpr int A_IMG = PL * 2 * TM * 1024;            // bytes of one stage's weight image
   constexpr int A16 = A_IMG / 16;
   constexpr int EA = (A16 + NT - 1) / NT;
   constexpr int BI = (FT * 32 * 4 + NT - 1) / NT;      // staging items (position, 8-channel group) per thread
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int V = a.V, T = a.T;
   const int PT = FT * V;                               // positions of the frame tile
-  const int B_IMG = 3 * 4 * PT * 16;                   // bytes: [plane][ks][h][pos][8]
+  const int B_IMG = PL * 4 * PT * 16;                  // bytes: [plane][ks][h][pos][8]
+  float rs_s = 1.f, rs_inv = 1.f;
+  if constexpr (F16) f16_range_scale(a.dy_absmax, rs_s, rs_inv);
   unsigned char* abuf = smem;                          // [2][A_IMG]
   unsigned char* bbuf = smem + 2 * A_IMG;              // [2][B_IMG]
 
@@ -747,14 +755,15 @@ __global__ void __launch_bounds__(NW * 64, 2) gcn_dadj_chain_kernel(const DadjAr
         u32x4 ph, pm, pl;
 #pragma unroll
         for (int e2 = 0; e2 < 4; ++e2) {
-          unsigned q0, q1, q2;
-          split_pair(rb[2 * e2][q], rb[2 * e2 + 1][q], q0, q1, q2);
+          unsigned q0, q1, q2 = 0;
+          if constexpr (F16) split_pair_f16(rb[2 * e2][q] * rs_s, rb[2 * e2 + 1][q] * rs_s, q0, q1);
+          else split_pair(rb[2 * e2][q], rb[2 * e2 + 1][q], q0, q1, q2);
           ph[e2] = q0; pm[e2] = q1; pl[e2] = q2;
         }
         if (pos + q < PT) {
           *reinterpret_cast<u32x4*>(bd + ((0 * 4 + og) * PT + pos + q) * 16) = ph;
           *reinterpret_cast<u32x4*>(bd + ((1 * 4 + og) * PT + pos + q) * 16) = pm;
-          *reinterpret_cast<u32x4*>(bd + ((2 * 4 + og) * PT + pos + q) * 16) = pl;
+          if constexpr (!F16) *reinterpret_cast<u32x4*>(bd + ((2 * 4 + og) * PT + pos + q) * 16) = pl;
         }
       }
     }
@@ -785,18 +794,24 @@ __global__ void __launch_bounds__(NW * 64, 2) gcn_dadj_chain_kernel(const DadjAr
       const unsigned char* bb = bbuf + (s & 1) * B_IMG;
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks) {
-        bf16x8 b[3];
+        bf16x8 b[PL];
 #pragma unroll
-        for (int pl = 0; pl < 3; ++pl)
+        for (int pl = 0; pl < PL; ++pl)
           b[pl] = *reinterpret_cast<const bf16x8*>(bb + (((pl * 2 + ks) * 2 + h) * PT + bpos) * 16);
 #pragma unroll
         for (int tm = 0; tm < TM; ++tm) {
           const bf16x8 a0 = *reinterpret_cast<const bf16x8*>(ab + ((0 * 2 + ks) * TM + tm) * 1024);
           const bf16x8 a1 = *reinterpret_cast<const bf16x8*>(ab + ((1 * 2 + ks) * TM + tm) * 1024);
-          const bf16x8 a2 = *reinterpret_cast<const bf16x8*>(ab + ((2 * 2 + ks) * TM + tm) * 1024);
+          if constexpr (F16) {
+            acc[tm] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a1), __builtin_bit_cast(f16x8, b[0]), acc[tm], 0, 0, 0);
+            acc[tm] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a0), __builtin_bit_cast(f16x8, b[1]), acc[tm], 0, 0, 0);
+            acc[tm] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a0), __builtin_bit_cast(f16x8, b[0]), acc[tm], 0, 0, 0);
+            continue;
+          }
+          const bf16x8 a2 = *reinterpret_cast<const bf16x8*>(ab + ((PL - 1) * 2 + ks) * TM * 1024 + tm * 1024);
           if (a.npl == 3) {
             acc[tm] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, b[0], acc[tm], 0, 0, 0);
-            acc[tm] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b[2], acc[tm], 0, 0, 0);
+            acc[tm] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b[PL - 1], acc[tm], 0, 0, 0);
             acc[tm] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b[1], acc[tm], 0, 0, 0);
             acc[tm] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b[0], acc[tm], 0, 0, 0);
             acc[tm] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b[1], acc[tm], 0, 0, 0);
@@ -831,7 +846,7 @@ __global__ void __launch_bounds__(NW * 64, 2) gcn_dadj_chain_kernel(const DadjAr
 #pragma unroll
   for (int j = 0; j < 16; ++j) {
     const int u = mfma_row(j, h);
-    if (u < V && lr < V) red[wave * VV + u * V + lr] = d[j];
+    if (u < V && lr < V) red[wave * VV + u * V + lr] = F16 ? d[j] * rs_inv : d[j];
   }
   __syncthreads();
   const int slot = tile_id * a.gpc + (mbk - isub * a.gpc);
@@ -844,29 +859,37 @@ __global__ void __launch_bounds__(NW * 64, 2) gcn_dadj_chain_kernel(const DadjAr
   }
 }
 
-template <int TM, int NW>
+template <int TM, int NW, bool F16 = false>
 int dadj_chain_launch(DadjArgs a, const float* wcat, void* ws, size_t ws_bytes, hipStream_t stream) {
   constexpr int BM = TM * 32, FT = NW;
+  constexpr int PL = F16 ? 2 : 3;
   a.ntiles = (a.T + FT - 1) / FT;
   a.nkc = (a.Cout + KC - 1) / KC;
   a.gpc = a.C / BM;
   a.nmb = 3 * a.gpc;
   a.nslots = a.ntiles * a.gpc;
-  const size_t a_img = (size_t)3 * 2 * TM * 1024;
-  const size_t b_img = (size_t)3 * 4 * FT * a.V * 16;
+  const size_t a_img = (size_t)PL * 2 * TM * 1024;
+  const size_t b_img = (size_t)PL * 4 * FT * a.V * 16;
   size_t smem_bytes = 2 * a_img + 2 * b_img;
   const size_t epi = (size_t)NW * a.V * a.V * 4;
   if (epi > smem_bytes) smem_bytes = epi;
   if (smem_bytes > 160 * 1024) return AGCN_ERR_UNSUPPORTED;
   const size_t pack_bytes = (size_t)a.nmb * a.nkc * a_img;
-  if (pack_bytes > ws_bytes) return AGCN_ERR_WORKSPACE;
+  if (pack_bytes + (F16 ? 16 : 0) > ws_bytes) return AGCN_ERR_WORKSPACE;
   a.wp = (const unsigned short*)ws;
+  if constexpr (F16) {
+    if (!a.dy_absmax) {      // behind the (two-plane) weight images of a workspace sized for three planes
+      unsigned* amax = reinterpret_cast<unsigned*>(static_cast<char*>(ws) + pack_bytes);
+      if (int rc = agcn_launch_absmax(a.dy, (long)a.N * a.Cout * a.T * a.V, amax, stream)) return rc;
+      a.dy_absmax = reinterpret_cast<const float*>(amax);
+    }
+  }
   DadjPackArgs pk;
   pk.w = wcat; pk.wp = (unsigned short*)ws; pk.C3 = 3 * a.C; pk.Cout = a.Cout; pk.nkc = a.nkc;
-  hipLaunchKernelGGL((dadj_pack_kernel<TM>), dim3(a.nmb * a.nkc), dim3(256), 0, stream, pk);
+  hipLaunchKernelGGL((dadj_pack_kernel<TM, F16>), dim3(a.nmb * a.nkc), dim3(256), 0, stream, pk);
   int rc = agcn_check_launch();
   if (rc) return rc;
-  auto kern = gcn_dadj_chain_kernel<TM, NW>;
+  auto kern = gcn_dadj_chain_kernel<TM, NW, F16>;
   static unsigned char lds_ok[AGCN_MAX_DEVICES] = {};   // per (kernel instantiation, device): the attribute is per device
   if (int e = agcn_allow_big_lds_rt(reinterpret_cast<const void*>(kern), lds_ok)) return e;
   hipLaunchKernelGGL(kern, dim3((unsigned)(a.N * a.ntiles * a.nmb)), dim3(NW * 64), smem_bytes, stream, a);
@@ -956,10 +979,16 @@ size_t agcn_gcn_dadj_chain_workspace(int C, int Cout) {
 }
 
 int agcn_gcn_dadj_chain(const float* dy, const float* wcat, const float* x, float* dadj_part, void* ws, size_t ws_bytes,
-                        int N, int C, int Cout, int T, int V, hipStream_t stream) {
+                        int N, int C, int Cout, int T, int V, hipStream_t stream, const float* dy_absmax) {
   DadjArgs a = {};
   a.npl = agcn_npl();
   a.dy = dy; a.x = x; a.dpart = dadj_part; a.N = N; a.C = C; a.Cout = Cout; a.T = T; a.V = V;
+  a.dy_absmax = dy_absmax;
+  static const int f16 = getenv("AGCN_DADJ_F16X3") ? atoi(getenv("AGCN_DADJ_F16X3")) : 1;   // 0: bf16x6 (A/B)
+  if (agcn_chain_f16x3() && f16) {
+    if (C % 128 == 0) return dadj_chain_launch<4, DADJ_NW, true>(a, wcat, ws, ws_bytes, stream);
+    return dadj_chain_launch<2, DADJ_NW64, true>(a, wcat, ws, ws_bytes, stream);
+  }
   if (C % 128 == 0) return dadj_chain_launch<4, DADJ_NW>(a, wcat, ws, ws_bytes, stream);
   return dadj_chain_launch<2, DADJ_NW64>(a, wcat, ws, ws_bytes, stream);
 }

@@ -94,8 +94,9 @@ def pmc_traffic(kernel):
 
 
 def dominant_kernel_roofline(device, reps=10):
-    """The kernel family with the largest share of the step (profiles/*_kernel_stats.txt: conv_gemm_bf16_kernel over
-    its instantiations): unit_tcn's 9x1 temporal convolution, timed as the forward at the l9/l10 shape (N'=128,
+    """The operator with the largest share of the step (profiles/*_kernel_stats.txt: the temporal convolution's
+    conv_pc_kernel + conv_gemm_bf16_kernel + wgrad9_bf16_kernel; the unit_gcn chain gcn_chain_kernel comes next and is
+    covered per layer by `unit_gcn_fwd`): unit_tcn's 9x1 temporal convolution, timed as the forward at the l9/l10 shape (N'=128,
     C=Cout=256, T=75, V=25) with HIP events on the stream it is launched on.  Algorithmic work per launch:
     2*Cout*Cin*9 FLOP per output position x 128*75*25 positions = 283.1 GFLOP (fp32-equivalent) and 491.5 MB.
     Arithmetic and ceiling follow the mode the library reports (agcn_gemm_mode): bf16x6 = every fp32 product is 6 bf16
@@ -157,9 +158,10 @@ def unit_gcn_forward_roofline(device, reps=5, Np=128, V=25):
     with HIP events on the launch stream.  Algorithmic work per SURVEY 8(d): FLOPs = theta/phi + S + aggregate +
     project (+ down); bytes = read x once + write y once.  Two roofline times are given:
       * `roofline_ms` / `frac`: per-phase-consistent -- every phase priced at the peak of the arithmetic it actually
-        runs in this build (`phases`): bf16x6 split MFMA (2500/6 = 416.7 TFLOP/s fp32-equivalent) for the theta/phi
-        and conv_d projections, exact-f32 MFMA (157.3) for the score reduction, the aggregation chain and the 1x1
-        `down` convolution; roofline = max(bytes / 8 TB/s, sum_phase FLOPs_phase / peak_phase);
+        runs in this build (`phases`): f16x3 split MFMA (2500/3 = 833.3 TFLOP/s fp32-equivalent; agcn_chain_mode) for
+        the aggregation and the conv_d projection of the chained layers, bf16x6 (2500/6 = 416.7) for the theta/phi
+        projections, exact-f32 MFMA (157.3) for the score reduction, the 1x1 `down` convolution and the un-chained
+        first layer; roofline = max(bytes / 8 TB/s, sum_phase FLOPs_phase / peak_phase);
       * `roofline_f32_ms` / `frac_f32`: SURVEY 8(d)'s definition, all FLOPs at the 157.3 TFLOP/s f32 matrix rate."""
     import agcn_amd  # noqa: F401
     from agcn_amd import ops
@@ -169,6 +171,9 @@ def unit_gcn_forward_roofline(device, reps=5, Np=128, V=25):
     mode = ops._L().agcn_gemm_mode().decode()
     split_peak = (PEAK_FP32_MFMA_TFLOPS if mode == 'f32' else
                   PEAK_BF16_MFMA_TFLOPS / {'bf16x6': 6, 'bf16x3': 3, 'bf16': 1}[mode])
+    chain_mode = ops._L().agcn_chain_mode().decode()       # arithmetic of the aggregate+project chain
+    chain_peak = PEAK_BF16_MFMA_TFLOPS / 3 if chain_mode == 'f16x3' else split_peak
+    chain_agg_split = os.environ.get('AGCN_CHAIN_F32', '0') == '0' and mode == 'bf16x6'   # aggregation on split MFMA too
     rows = []
     for name, C, Cout, T in GCN_LAYER_SHAPES:
         torch.manual_seed(0)
@@ -193,8 +198,8 @@ def unit_gcn_forward_roofline(device, reps=5, Np=128, V=25):
         ph = {  # phase: (FLOPs, peak TFLOP/s of the arithmetic it runs in)
             'theta_phi': (Np * 6 * 2 * C * Ci * T * V, split_peak if fused_adj else PEAK_FP32_MFMA_TFLOPS),
             'scores': (Np * 3 * 2 * V * V * Ci * T, PEAK_FP32_MFMA_TFLOPS),
-            'aggregate': (Np * 3 * 2 * C * T * V * V, PEAK_FP32_MFMA_TFLOPS),
-            'project': (Np * 3 * 2 * C * Cout * T * V, split_peak if chained else PEAK_FP32_MFMA_TFLOPS),
+            'aggregate': (Np * 3 * 2 * C * T * V * V, chain_peak if chained and chain_agg_split else PEAK_FP32_MFMA_TFLOPS),
+            'project': (Np * 3 * 2 * C * Cout * T * V, chain_peak if chained else PEAK_FP32_MFMA_TFLOPS),
             'down': (Np * 2 * C * Cout * T * V if C != Cout else 0, PEAK_FP32_MFMA_TFLOPS)}
         flops = sum(f for f, _ in ph.values())
         nbytes = 4.0 * Np * (C + Cout) * T * V
@@ -361,8 +366,9 @@ def main():
                        "parallelism": f"dp{world}", "bn": "sync (reference DDP semantics)" if sync_bn else "per-replica",
                        "gemm_arithmetic": gemm_mode + (" (every fp32 product = 6 bf16 MFMA products, fp32 accumulate: "
                                                        "fp32-equivalent, dropped terms < 2^-24 |ab|; the temporal "
-                                                       "convolutions' forward and backward-data: 3 fp16 products on "
-                                                       "max-normalised operands, dropped terms < 2^-22 |ab|)"
+                                                       "convolutions' and the aggregate+project chain's forward and "
+                                                       "backward-data: 3 fp16 products on max-normalised operands, "
+                                                       "dropped terms < 2^-22 |ab|)"
                                                        if gemm_mode == 'bf16x6' else
                                                        " (exact-f32 MFMA)" if gemm_mode == 'f32' else
                                                        " (plain bf16 MFMA operands, one product per fp32 product, fp32 "
