@@ -179,8 +179,11 @@ __global__ void dpa_reduce_kernel(const float* __restrict__ dadj, float* __restr
 // (dS already carries the 1/K).  Also per-row sums for the conv_a/conv_b bias gradients.
 __global__ void __launch_bounds__(256, 3)
 scores_bwd_kernel(const float* __restrict__ tp, const float* __restrict__ dS, float* __restrict__ dtp,
-                  float* __restrict__ dbpart, int N, int Ci, int T, int V, int tt, int ntiles) {
+                  float* __restrict__ dbpart, unsigned* __restrict__ amax, int N, int Ci, int T, int V, int tt,
+                  int ntiles) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
+  __shared__ unsigned wmax[4];
+  unsigned mx = 0;                       // max |dtp| over what this thread stores (bit pattern: unsigned order = float order)
   const int ttv = tt * V;
   const int VS = (V + 1) >> 1, VP = 2 * VS;
   float* Th = smem;                      // [SC_CK*tt][V]
@@ -304,7 +307,11 @@ scores_bwd_kernel(const float* __restrict__ tp, const float* __restrict__ dS, fl
             if (okr && q + 3 < nvalid) {
               f32x4 val;
 #pragma unroll
-              for (int e = 0; e < 4; ++e) { val[e] = buf[cl * ttv + q + e]; sum += val[e]; }
+              for (int e = 0; e < 4; ++e) {
+                val[e] = buf[cl * ttv + q + e];
+                sum += val[e];
+                mx = max(mx, __builtin_bit_cast(unsigned, val[e]) & 0x7fffffffu);
+              }
               *reinterpret_cast<f32x4_u*>(drow + q) = val;
             } else if (okr) {
 #pragma unroll
@@ -313,6 +320,7 @@ scores_bwd_kernel(const float* __restrict__ tp, const float* __restrict__ dS, fl
                   const float val = buf[cl * ttv + q + e];
                   drow[q + e] = val;
                   sum += val;
+                  mx = max(mx, __builtin_bit_cast(unsigned, val) & 0x7fffffffu);
                 }
             }
           }
@@ -345,6 +353,7 @@ scores_bwd_kernel(const float* __restrict__ tp, const float* __restrict__ dS, fl
           const int cl = r2 / tt, t_l = r2 - cl * tt;
           const bool ok = r2 < nrows && (c0 + cl) < Ci && t_l < tvalid;
           const float val = (ok && lr < V) ? d[j] : 0.f;
+          mx = max(mx, __builtin_bit_cast(unsigned, val) & 0x7fffffffu);
           if (ok && lr < V)
             dtp[(row0 + (long)which * Ci + c0 + cl) * P + (long)(t0 + t_l) * V + lr] = val;
           const float rs = half_sum(val);
@@ -362,6 +371,18 @@ scores_bwd_kernel(const float* __restrict__ tp, const float* __restrict__ dS, fl
           dbpart[((long)n * ntiles + tile) * 6 * Ci + (long)i * 2 * Ci + (long)which * Ci + c0 + cl] = s;
         }
       }
+    }
+  }
+  if (amax) {
+    // one atomic per workgroup at most, none once the running maximum has passed this workgroup's (a stale read only
+    // costs a redundant atomic: the value can only grow)
+#pragma unroll
+    for (int k = 32; k >= 1; k >>= 1) mx = max(mx, (unsigned)__shfl_xor((int)mx, k));
+    if (lane == 0) wmax[wave] = mx;
+    __syncthreads();
+    if (tid == 0) {
+      const unsigned m = max(max(wmax[0], wmax[1]), max(wmax[2], wmax[3]));
+      if (m > __hip_atomic_load(amax, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(amax, m);
     }
   }
 }
@@ -420,16 +441,24 @@ int agcn_adjacency_bwd_softmax(const float* dadj_part, const float* P, const flo
 }
 
 // dtp: (N,6Ci,T*V) ; dbpart: (N*ntiles, 6Ci) scratch ; scratch: agcn_colsum_scratch_bytes(6Ci) ; db: (6Ci)
+int agcn_adjacency_bwd_scores_ex(const float* tp, const float* dS, float* dtp, float* dbpart, void* scratch, float* db,
+                                 float* dtp_absmax_out, int N, int Ci, int T, int V, void* stream);
 int agcn_adjacency_bwd_scores(const float* tp, const float* dS, float* dtp, float* dbpart, void* scratch, float* db,
                               int N, int Ci, int T, int V, void* stream) {
+  return agcn_adjacency_bwd_scores_ex(tp, dS, dtp, dbpart, scratch, db, nullptr, N, Ci, T, V, stream);
+}
+// dtp_absmax_out (or NULL): device scalar that receives max |dtp| for the f16x3 kernels that read dtp next
+int agcn_adjacency_bwd_scores_ex(const float* tp, const float* dS, float* dtp, float* dbpart, void* scratch, float* db,
+                                 float* dtp_absmax_out, int N, int Ci, int T, int V, void* stream) {
   if (!tp || !dS || !dtp || !dbpart || !scratch || !db || N <= 0 || Ci <= 0 || T <= 0 || V <= 0 || V > 32)
     return AGCN_ERR_ARG;
   hipStream_t s = (hipStream_t)stream;
   const int tt = sc_tile_frames(V, T), ntiles = (T + tt - 1) / tt;
   const int VP = 2 * ((V + 1) / 2);
   const size_t smem = 4 * ((size_t)2 * SC_CK * tt * V + 2 * VP * 32 + 2 * SC_CK * tt);
-  hipLaunchKernelGGL(scores_bwd_kernel, dim3(N * ntiles, 3), dim3(256), smem, s, tp, dS, dtp, dbpart, N, Ci, T, V, tt,
-                     ntiles);
+  if (dtp_absmax_out && hipMemsetAsync(dtp_absmax_out, 0, 4, s) != hipSuccess) return AGCN_ERR_ARG;
+  hipLaunchKernelGGL(scores_bwd_kernel, dim3(N * ntiles, 3), dim3(256), smem, s, tp, dS, dtp, dbpart,
+                     reinterpret_cast<unsigned*>(dtp_absmax_out), N, Ci, T, V, tt, ntiles);
   int rc = agcn_check_launch();
   if (rc) return rc;
   return agcn_colsum(dbpart, N * ntiles, 6 * Ci, scratch, db, stream);

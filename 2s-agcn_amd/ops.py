@@ -295,7 +295,8 @@ def project_bwd_weight(dy, x, adj, Cout):
 
 
 def adjacency_bwd(dy, wcat, x, tp, P, alpha=None, wab=None, bab=None, dy_amax=None):
-    """Gradient of the adaptive adjacency branch.  Returns dPA (3,V,V), dtp (N,6Ci,T,V), dbab (6Ci), dalpha.
+    """Gradient of the adaptive adjacency branch.  Returns dPA (3,V,V), dtp (N,6Ci,T,V), dbab (6Ci), dalpha, dadj and
+    the device scalar max |dtp| its producer left behind (None where it does not: the consumers take it themselves).
     tp = None: theta/phi were never stored (adjacency_fused_fwd); they are recomputed from x, wab, bab on chip."""
     N, C, T, V = x.shape
     Cout = wcat.shape[0]
@@ -317,6 +318,7 @@ def adjacency_bwd(dy, wcat, x, tp, P, alpha=None, wab=None, bab=None, dy_amax=No
     dbpart = _empty((N * nt, 6 * Ci), x)
     dbab = _empty((6 * Ci,), x)
     scratch = _scratch(6 * Ci, x)
+    dtp_amax = None
     if tp is None:
         nb = _L().agcn_adjacency_fused_workspace(C, Ci)
         ws = _ws(nb, x)
@@ -325,11 +327,13 @@ def adjacency_bwd(dy, wcat, x, tp, P, alpha=None, wab=None, bab=None, dy_amax=No
             scratch.data_ptr(), _lib.ptr(dbab), ws.data_ptr(), nb, N, C, Ci, T, V, _lib.stream()),
             "agcn_adjacency_fused_bwd_scores")
     else:
-        _lib.check(_L().agcn_adjacency_bwd_scores(_lib.ptr(tp), _lib.ptr(dS), _lib.ptr(dtp), _lib.ptr(dbpart),
-                                                  scratch.data_ptr(), _lib.ptr(dbab), N, Ci, T, V, _lib.stream()),
+        dtp_amax = _empty((1,), x) if fused_amax_enabled() else None
+        _lib.check(_L().agcn_adjacency_bwd_scores_ex(_lib.ptr(tp), _lib.ptr(dS), _lib.ptr(dtp), _lib.ptr(dbpart),
+                                                     scratch.data_ptr(), _lib.ptr(dbab), _lib.ptr(dtp_amax), N, Ci, T, V,
+                                                     _lib.stream()),
                    "agcn_adjacency_bwd_scores")
     dalpha = dal_part.sum() if dal_part is not None else None
-    return dPA, dtp, dbab, dalpha, dadj
+    return dPA, dtp, dbab, dalpha, dadj, dtp_amax
 
 
 def stc_row_reduce(y, g=None, wv=None, wt=None, want_t=False, want_v=False, scale_t=1.0, scale_v=1.0):
@@ -688,13 +692,16 @@ def gcn_backward(c, dout, extra_add=None, extra_mask=None):
     dypre, dg1, db1, ddpre, dg2, db2 = bn_bwd(dout, c.g_bits, ypre, gamma1, c.g_bn1, dpre, gamma2, c.g_bn2,
                                               sync=c.g_sync, gcount=c.g_count, amax_out=dy_amax)
     dwd = _side_run(lambda: project_bwd_weight(dypre, x, adj, Cout), (dypre, x, adj))
-    dPA = dwab = dbab = dalpha = dtp = None
+    dPA = dwab = dbab = dalpha = dtp = dtp_amax = None
     if c.g_adaptive:      # adjacency branch first: its dtp rides along in the dx kernel where that is supported
-        dPA, dtp, dbab, dalpha, _ = adjacency_bwd(dypre, wd, x, tp, P, c.g_alpha, wab, c.g_bab, dy_amax=dy_amax)
+        dPA, dtp, dbab, dalpha, _, dtp_amax = adjacency_bwd(dypre, wd, x, tp, P, c.g_alpha, wab, c.g_bab,
+                                                            dy_amax=dy_amax)
         dwab = _side_run(lambda: conv_bwd_weight(dtp, x, wab.shape), (dtp, x))
     fuse = dtp is not None and fused_bwd_data_supported(x.shape[1], Cout, x.shape[3])
     ftp = dict(dtp=dtp, wab=wab) if fuse else {}
     ftp['dy_amax'] = dy_amax
+    if fuse:
+        ftp['dtp_amax'] = dtp_amax
     if dpre is None:      # identity `down`: dx += dout * (out > 0)
         dx = aggregate_project_bwd_data(dypre, adj, wd, x.shape, add1=dout, mask1=c.g_bits, add2=extra_add,
                                         mask2=extra_mask, **ftp)
