@@ -94,7 +94,8 @@ int agcn_gcn_dadj_chain(const float* dy, const float* wcat, const float* x, floa
 bool agcn_wgrad_chain_supported(int M, int C, int V);
 size_t agcn_wgrad_chain_workspace(int agg, int N, int M, int C, int V, int T_out);
 int agcn_wgrad_chain(int agg, const float* dy, const float* x, const float* adj, void* ws, size_t ws_bytes, int* nslabs,
-                     int N, int M, int C, int V, int T_src, int T_out, int stride, hipStream_t s);
+                     int N, int M, int C, int V, int T_src, int T_out, int stride, hipStream_t s,
+                     const float* dy_absmax = nullptr, const float* x_absmax = nullptr);
 
 // split-bf16 weight gradient of the 9-tap temporal convolution (wgrad9_bf16.hip): slabs [nslabs][9][M][C] at ws
 bool agcn_wgrad9_bf16_supported(int M, int C, int V, int stride);

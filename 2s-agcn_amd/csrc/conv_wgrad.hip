@@ -367,10 +367,11 @@ size_t ws_wgrad(int N, int M, int C, int V, int T_out, int stride, long wsize) {
 }
 
 // split-bf16 path (wgrad_chain.hip) + the same fixed-order slab reduction
-int chain_wgrad_and_reduce(int agg, const WgradArgs& a, float* dw, void* ws, size_t ws_bytes, hipStream_t stream) {
+int chain_wgrad_and_reduce(int agg, const WgradArgs& a, float* dw, void* ws, size_t ws_bytes, hipStream_t stream,
+                           const float* dy_absmax = nullptr, const float* x_absmax = nullptr) {
   int nslabs = 0;
   int rc = agcn_wgrad_chain(agg, a.dy, a.in, a.adj, ws, ws_bytes, &nslabs, a.N, a.M, a.C, a.V, a.T_src, a.T_out,
-                            a.stride, stream);
+                            a.stride, stream, dy_absmax, x_absmax);
   if (rc) return rc;
   return launch_reduce((const float*)ws, dw, a.wsize, nslabs, a.M, a.C, a.so_m, a.so_t, a.so_c, stream);
 }
@@ -422,8 +423,19 @@ size_t agcn_conv_bwd_weight_workspace(int N, int Cin, int Cout, int T, int V, in
 }
 
 // dw[o][c][k] = sum_{n,t,v} dy[n][o][t,v] * x[n][c][(t*stride + k - pad), v]
+int agcn_conv_bwd_weight_ex(const float* dy, const float* x, float* dw, void* workspace, size_t workspace_bytes, int N,
+                            int Cin, int Cout, int T, int V, int taps, int stride, const float* dy_absmax,
+                            const float* x_absmax, void* stream);
 int agcn_conv_bwd_weight(const float* dy, const float* x, float* dw, void* workspace, size_t workspace_bytes, int N,
                          int Cin, int Cout, int T, int V, int taps, int stride, void* stream) {
+  return agcn_conv_bwd_weight_ex(dy, x, dw, workspace, workspace_bytes, N, Cin, Cout, T, V, taps, stride, nullptr, nullptr,
+                                 stream);
+}
+// dy_absmax / x_absmax: device scalars max |dy| / max |x| their producers left behind; with BOTH given the tap-free
+// gradient (taps = 1, stride 1, Cin a multiple of 64) runs on f16x3, otherwise on bf16x6 as before (no pass of its own)
+int agcn_conv_bwd_weight_ex(const float* dy, const float* x, float* dw, void* workspace, size_t workspace_bytes, int N,
+                            int Cin, int Cout, int T, int V, int taps, int stride, const float* dy_absmax,
+                            const float* x_absmax, void* stream) {
   if (!dy || !x || !dw || !workspace || N <= 0 || Cin <= 0 || Cout <= 0 || T <= 0 || V <= 0 || V > 32)
     return AGCN_ERR_ARG;
   if ((taps != 1 && taps != 9) || (stride != 1 && stride != 2)) return AGCN_ERR_UNSUPPORTED;
@@ -448,7 +460,7 @@ int agcn_conv_bwd_weight(const float* dy, const float* x, float* dw, void* works
     return launch_wgrad<9, 0, 2, 2, 2, false, 7>(a, dw, workspace, workspace_bytes, s);
   }
   if (chain_wgrad_enabled() && agcn_wgrad_chain_supported(Cout, Cin, V))
-    return chain_wgrad_and_reduce(0, a, dw, workspace, workspace_bytes, s);
+    return chain_wgrad_and_reduce(0, a, dw, workspace, workspace_bytes, s, dy_absmax, x_absmax);
   if (Cout % 128 == 0) return launch_wgrad<1, 0, 4, 2, 1, false, 4>(a, dw, workspace, workspace_bytes, s);
   return launch_wgrad<1, 0, 2, 2, 2, true, 4>(a, dw, workspace, workspace_bytes, s);
 }
@@ -465,8 +477,18 @@ size_t agcn_gcn_project_bwd_weight_workspace(int N, int C, int Cout, int T, int 
 }
 
 // dwcat[o][i*C+c] = sum_{n,t,v} dy[n][o][t,v] * sum_u x[n][c][t,u] adj[n][i][u][v]
+int agcn_gcn_project_bwd_weight_ex(const float* dy, const float* x, const float* adj, float* dwcat, void* workspace,
+                                   size_t workspace_bytes, int N, int C, int Cout, int T, int V, const float* dy_absmax,
+                                   const float* x_absmax, void* stream);
 int agcn_gcn_project_bwd_weight(const float* dy, const float* x, const float* adj, float* dwcat, void* workspace,
                                 size_t workspace_bytes, int N, int C, int Cout, int T, int V, void* stream) {
+  return agcn_gcn_project_bwd_weight_ex(dy, x, adj, dwcat, workspace, workspace_bytes, N, C, Cout, T, V, nullptr, nullptr,
+                                        stream);
+}
+// with BOTH maxima given (and C a multiple of 64) the contraction runs on f16x3, otherwise on bf16x6 as before
+int agcn_gcn_project_bwd_weight_ex(const float* dy, const float* x, const float* adj, float* dwcat, void* workspace,
+                                   size_t workspace_bytes, int N, int C, int Cout, int T, int V, const float* dy_absmax,
+                                   const float* x_absmax, void* stream) {
   if (!dy || !x || !adj || !dwcat || !workspace || N <= 0 || C <= 0 || Cout <= 0 || T <= 0 || V <= 0 || V > 32)
     return AGCN_ERR_ARG;
   WgradArgs a = {};
@@ -474,7 +496,7 @@ int agcn_gcn_project_bwd_weight(const float* dy, const float* x, const float* ad
   a.so_m = 3L * C; a.so_t = C; a.so_c = 1; a.wsize = 3L * Cout * C;
   hipStream_t s = (hipStream_t)stream;
   if (chain_wgrad_enabled() && agcn_wgrad_chain_supported(Cout, C, V))
-    return chain_wgrad_and_reduce(1, a, dwcat, workspace, workspace_bytes, s);
+    return chain_wgrad_and_reduce(1, a, dwcat, workspace, workspace_bytes, s, dy_absmax, x_absmax);
   if (Cout % 128 == 0) return launch_wgrad<1, 1, 4, 2, 1, false, 2>(a, dwcat, workspace, workspace_bytes, s);
   return launch_wgrad<1, 1, 2, 2, 2, true, 2>(a, dwcat, workspace, workspace_bytes, s);
 }

@@ -12,6 +12,7 @@
 // Waves = NCB channel blocks x NFG frame groups; every frame group writes its own partial slab (split-K), summed by
 // the fixed-order wgrad_reduce kernel of conv_wgrad.hip.
 #include "agcn_common.h"
+#include "split_f16.h"
 
 namespace {
 
@@ -33,6 +34,8 @@ struct WcArgs {
   int npl;             // 3: six split products (bf16x6) ; 1: hi*hi only (bf16)
   int dbg;             // profiling switches (AGCN_WC_DBG): 1 = no matrix work, 2 = stage the first pair only, 4 = no f32 chain
   int pad;             // 1: [o] blocks of the dy image padded by one slot (AGCN_WC_PAD=0 for the A/B measurement)
+  const float* dy_absmax;   // f16x3 (wgrad_pc_kernel<..., true>): device scalars max |dy|, max |in| for the range scales
+  const float* in_absmax;
 };
 
 __device__ __forceinline__ unsigned wc_pack_bf16(float a, float b) {
@@ -306,8 +309,13 @@ __global__ void __launch_bounds__(NW * 64, 2) wgrad_chain_kernel(const WcArgs a)
 // AGG: the workgroup handles all three subsets (dy and x staged once, a third of the HBM/L2 traffic of one workgroup per
 // subset: measured, that variant ran at the memory system's pace); a consumer wave then holds 3*TM accumulator tiles.
 // NRB: 32*TM-row blocks per workgroup (consumer waves = NCB channel blocks x NFG frames x NRB row blocks)
-template <int AGG, int TM, int NCB, int VS, int NRB = 1, int NWC = 8, int NWP = 4>
+// F16: the contraction on f16x3 (split_f16.h): dy is scaled so that max |dy| lands in [2^14, 2^15) while the producers
+// split it, G (= x, or x . A^ from the exact-f32 chain) so that max |x| lands in [2^8, 2^9) (headroom for the adjacency's
+// column sums) while the consumers split it; the slabs are un-scaled when stored.
+template <int AGG, int TM, int NCB, int VS, int NRB = 1, int NWC = 8, int NWP = 4, bool F16 = false>
 __global__ void __launch_bounds__((NWC + NWP) * 64, (NWC + NWP) / 4) wgrad_pc_kernel(const WcArgs a) {
+  static_assert(!F16 || !(AGG && VS == 0), "the f16x3 variant keeps the aggregation on the exact-f32 chain");
+  constexpr int PL = F16 ? 2 : 3, NPROD = F16 ? 3 : 6;
   constexpr int NTP = NWP * 64, BM = TM * 32 * NRB;
   constexpr int NS = AGG ? 3 : 1;
   constexpr int NFG = NWC / (NCB * NRB);        // frame groups = frames per stage (one frame per consumer wave)
@@ -316,10 +324,15 @@ __global__ void __launch_bounds__((NWC + NWP) * 64, (NWC + NWP) / 4) wgrad_pc_ke
   constexpr int DI = BM * FT * 4 / NTP;         // dy items (o, f, ks, h) per producer thread
   static_assert(BM * FT * 4 % NTP == 0, "dy items must tile the producer threads");
   constexpr int BMP = BM + 1;
-  constexpr int DY_BYTES = 3 * FT * 4 * BMP * 16;
+  constexpr int DY_BYTES = PL * FT * 4 * BMP * 16;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int V = a.V, XP = a.XP;
   const int FTV = FT * V;
+  float s_dy = 1.f, inv_dy = 1.f, s_x = 1.f, inv_x = 1.f;
+  if constexpr (F16) {
+    f16_range_scale_of<14>(*a.dy_absmax, s_dy, inv_dy);
+    f16_range_scale_of<8>(*a.in_absmax, s_x, inv_x);
+  }
   // VS == 0: the aggregation chain runs on split-bf16 MFMA (12 MFMAs of 32 cycles for K = 32 joints instead of VS
   // exact-f32 steps of 64 cycles): adjacencies kept as bf16 planes [subset][plane][ks][h][v][8 u] (gcn_chain.hip)
   constexpr bool BCH = AGG && VS == 0;
@@ -413,14 +426,15 @@ __global__ void __launch_bounds__((NWC + NWP) * 64, (NWC + NWP) / 4) wgrad_pc_ke
         u32x4 ph, pm, pl;
 #pragma unroll
         for (int e2 = 0; e2 < 4; ++e2) {
-          unsigned q0, q1, q2;
-          wc_split_pair(rdy[k][2 * e2], rdy[k][2 * e2 + 1], q0, q1, q2);
+          unsigned q0, q1, q2 = 0;
+          if constexpr (F16) split_pair_f16(rdy[k][2 * e2] * s_dy, rdy[k][2 * e2 + 1] * s_dy, q0, q1);
+          else wc_split_pair(rdy[k][2 * e2], rdy[k][2 * e2 + 1], q0, q1, q2);
           ph[e2] = q0; pm[e2] = q1; pl[e2] = q2;
         }
         const int slot = r * BMP + o;             // r = (f*2 + ks)*2 + hh
         *reinterpret_cast<u32x4*>(dyi + ((0 * FT * 4) * BMP + slot) * 16) = ph;
         *reinterpret_cast<u32x4*>(dyi + ((1 * FT * 4) * BMP + slot) * 16) = pm;
-        *reinterpret_cast<u32x4*>(dyi + ((2 * FT * 4) * BMP + slot) * 16) = pl;
+        if constexpr (!F16) *reinterpret_cast<u32x4*>(dyi + ((2 * FT * 4) * BMP + slot) * 16) = pl;
       }
       const int piece = ptid & (LPR - 1), rsub = (ptid & 63) / LPR;
 #pragma unroll
@@ -573,29 +587,35 @@ __global__ void __launch_bounds__((NWC + NWP) * 64, (NWC + NWP) / 4) wgrad_pc_ke
           u32x4 gh, gm, gl;
 #pragma unroll
           for (int e2 = 0; e2 < 4; ++e2) {
-            unsigned q0, q1, q2;
-            wc_split_pair(d[8 * ks + 2 * e2], d[8 * ks + 2 * e2 + 1], q0, q1, q2);
+            unsigned q0, q1, q2 = 0;
+            if constexpr (F16) split_pair_f16(d[8 * ks + 2 * e2] * s_x, d[8 * ks + 2 * e2 + 1] * s_x, q0, q1);
+            else wc_split_pair(d[8 * ks + 2 * e2], d[8 * ks + 2 * e2 + 1], q0, q1, q2);
             gh[e2] = q0; gm[e2] = q1; gl[e2] = q2;
           }
           gb[ks][0] = __builtin_bit_cast(bf16x8, gh);
           gb[ks][1] = __builtin_bit_cast(bf16x8, gm);
           gb[ks][2] = __builtin_bit_cast(bf16x8, gl);
         }
-        // 2*TM steps of 6 MFMAs; the dy fragments of step s+1 are read while step s runs (order pinned below)
+        // 2*TM steps of 6 (f16x3: 3) MFMAs; the dy fragments of step s+1 are read while step s runs (order pinned below)
         auto load_a = [&](bf16x8 (&af)[3], int step) __attribute__((always_inline)) {
           const int ks = step / TM, tm = step - ks * TM;
 #pragma unroll
-          for (int pl = 0; pl < 3; ++pl)
+          for (int pl = 0; pl < PL; ++pl)
             af[pl] = *reinterpret_cast<const bf16x8*>(ab + ((pl * FT * 4 + ks * 2) * BMP + tm * 32) * 16);
         };
         bf16x8 afc[3];
         load_a(afc, 0);
-        __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, PL, 0);
 #pragma unroll
         for (int step = 0; step < 2 * TM; ++step) {
           const int ks = step / TM, tm = step - ks * TM;
           bf16x8 afn[3];
           if (step + 1 < 2 * TM) load_a(afn, step + 1);
+          if constexpr (F16) {
+            acc[sub][tm] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, afc[1]), __builtin_bit_cast(f16x8, gb[ks][0]), acc[sub][tm], 0, 0, 0);
+            acc[sub][tm] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, afc[0]), __builtin_bit_cast(f16x8, gb[ks][1]), acc[sub][tm], 0, 0, 0);
+            acc[sub][tm] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, afc[0]), __builtin_bit_cast(f16x8, gb[ks][0]), acc[sub][tm], 0, 0, 0);
+          } else {
           if (a.npl == 3) {
             acc[sub][tm] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afc[2], gb[ks][0], acc[sub][tm], 0, 0, 0);
             acc[sub][tm] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afc[0], gb[ks][2], acc[sub][tm], 0, 0, 0);
@@ -604,12 +624,13 @@ __global__ void __launch_bounds__((NWC + NWP) * 64, (NWC + NWP) / 4) wgrad_pc_ke
             acc[sub][tm] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afc[0], gb[ks][1], acc[sub][tm], 0, 0, 0);
           }
           acc[sub][tm] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afc[0], gb[ks][0], acc[sub][tm], 0, 0, 0);
-          if (step + 1 < 2 * TM) {
-            __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);
-#pragma unroll
-            for (int pl = 0; pl < 3; ++pl) afc[pl] = afn[pl];
           }
-          __builtin_amdgcn_sched_group_barrier(0x008, 6, 0);
+          if (step + 1 < 2 * TM) {
+            __builtin_amdgcn_sched_group_barrier(0x100, PL, 0);
+#pragma unroll
+            for (int pl = 0; pl < PL; ++pl) afc[pl] = afn[pl];
+          }
+          __builtin_amdgcn_sched_group_barrier(0x008, NPROD, 0);
         }
         __builtin_amdgcn_sched_barrier(0);       // keep the subsets apart (interleaving them costs registers)
       }
@@ -627,7 +648,7 @@ __global__ void __launch_bounds__((NWC + NWP) * 64, (NWC + NWP) / 4) wgrad_pc_ke
       for (int j = 0; j < 16; ++j) {
         const int m = m0 + (rb * TM + tm) * 32 + mfma_row(j, h);
         const int c = c0 + cbw * 32 + lr;
-        if (m < a.M && c < a.C) dst[(long)m * a.C + c] = acc[sub][tm][j];
+        if (m < a.M && c < a.C) dst[(long)m * a.C + c] = F16 ? acc[sub][tm][j] * (inv_dy * inv_x) : acc[sub][tm][j];
       }
   }
 }
@@ -732,14 +753,14 @@ size_t wc_slabs(int N, int M, int C, int V, int T_out) {
 
 // ---- producer / consumer variant: geometry, launch, dispatch ----
 template <int AGG, int TM, int NCB, int NRB>
-WcGeom wc_geom_pc(int N, int M, int C, int V, int T_out, bool bch = false) {
+WcGeom wc_geom_pc(int N, int M, int C, int V, int T_out, bool bch = false, int planes = 3) {
   constexpr int BM = TM * 32 * NRB, NFG = 8 / (NCB * NRB), FT = NFG, CG = NCB * 32;
   WcGeom g;
   g.ntiles = (T_out + FT - 1) / FT;
   g.ncg = (C + CG - 1) / CG;
   g.nmb = (M + BM - 1) / BM;
   g.XP = (FT * V) | 1;
-  g.smem_bytes = 2 * ((size_t)3 * FT * 4 * (BM + 1) * 16 + (((size_t)CG * g.XP * 4 + 15) & ~(size_t)15) +
+  g.smem_bytes = 2 * ((size_t)planes * FT * 4 * (BM + 1) * 16 + (((size_t)CG * g.XP * 4 + 15) & ~(size_t)15) +
                       (AGG ? (bch ? (size_t)3 * 3 * 2 * 2 * 32 * 16 : (size_t)3 * 32 * 32 * 4) : 0)) + 32;
   g.grid_x = g.nmb * g.ncg;
   const int pairs = N * g.ntiles;
@@ -752,8 +773,31 @@ WcGeom wc_geom_pc(int N, int M, int C, int V, int T_out, bool bch = false) {
   return g;
 }
 
+// AGCN_WGRAD_F16X3=0 keeps the weight gradients on bf16x6 (A/B)
+static inline bool wc_f16x3() {
+  static const int on = getenv("AGCN_WGRAD_F16X3") ? atoi(getenv("AGCN_WGRAD_F16X3")) : 1;
+  return on != 0;
+}
+
 template <int AGG, int TM, int NCB, int NRB, int VS, int NWP = 4>
 int wc_launch_pc(WcArgs a, void* ws, size_t ws_bytes, int* nslabs_out, hipStream_t stream) {
+  // f16x3 when the caller supplied both operand maxima (fp32-equivalent mode, exact-f32 aggregation chain)
+  if constexpr (!(AGG && VS == 0)) {
+    if (a.dy_absmax && a.in_absmax && a.npl == 3 && wc_f16x3()) {
+      const WcGeom g = wc_geom_pc<AGG, TM, NCB, NRB>(a.N, a.M, a.C, a.V, a.T_out, false, 2);
+      if (g.smem_bytes > 160 * 1024) return AGCN_ERR_UNSUPPORTED;
+      if ((size_t)g.nslabs * a.wsize * 4 > ws_bytes) return AGCN_ERR_WORKSPACE;
+      a.part = (float*)ws;
+      a.ntiles = g.ntiles; a.pairs_per_split = g.pairs_per_split; a.ncg = g.ncg; a.XP = g.XP;
+      auto kern = wgrad_pc_kernel<AGG, TM, NCB, VS, NRB, 8, NWP, true>;
+      static unsigned char lds_ok[AGCN_MAX_DEVICES] = {};
+      if (int e = agcn_allow_big_lds_rt(reinterpret_cast<const void*>(kern), lds_ok)) return e;
+      AGCN_NOTE_KERNEL("wgrad_pc_kernel<%d, %d, %d, %d, %d, 8, %d, true>", AGG, TM, NCB, VS, NRB, NWP);
+      hipLaunchKernelGGL(kern, dim3(g.grid_x, g.nsplit), dim3((8 + NWP) * 64), g.smem_bytes, stream, a);
+      *nslabs_out = g.nslabs;
+      return agcn_check_launch();
+    }
+  }
   const WcGeom g = wc_geom_pc<AGG, TM, NCB, NRB>(a.N, a.M, a.C, a.V, a.T_out, AGG && VS == 0);
   if (g.smem_bytes > 160 * 1024) return AGCN_ERR_UNSUPPORTED;
   if ((size_t)g.nslabs * a.wsize * 4 > ws_bytes) return AGCN_ERR_WORKSPACE;
@@ -850,8 +894,10 @@ size_t agcn_wgrad_chain_workspace(int agg, int N, int M, int C, int V, int T_out
 
 // writes the partial slabs into ws; *nslabs = number of slabs for the reduce kernel.  agg: x . adj_i operand, z = subset
 int agcn_wgrad_chain(int agg, const float* dy, const float* x, const float* adj, void* ws, size_t ws_bytes, int* nslabs,
-                     int N, int M, int C, int V, int T_src, int T_out, int stride, hipStream_t s) {
+                     int N, int M, int C, int V, int T_src, int T_out, int stride, hipStream_t s, const float* dy_absmax,
+                     const float* x_absmax) {
   WcArgs a = {};
+  a.dy_absmax = dy_absmax; a.in_absmax = x_absmax;
   a.npl = agcn_npl();
   { const char* e = getenv("AGCN_WC_PAD"); a.pad = (e && atoi(e) == 0) ? 0 : 1; }
   { const char* e = getenv("AGCN_WC_DBG"); a.dbg = e ? atoi(e) : 0; }

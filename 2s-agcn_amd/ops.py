@@ -157,14 +157,17 @@ def conv_bwd_data(dy, w, x_shape, stride=1, out=None, accumulate=False, add1=Non
     return dx
 
 
-def conv_bwd_weight(dy, x, w_shape, stride=1):
+def conv_bwd_weight(dy, x, w_shape, stride=1, dy_amax=None, x_amax=None):
+    """dy_amax / x_amax: device scalars max |dy| / max |x| left behind by their producers; with both, the tap-free
+    gradients run on f16x3 (agcn_conv_bwd_weight_ex)."""
     N, Cin, T, V = x.shape
     Cout, _, taps, _ = w_shape
     nbytes = _L().agcn_conv_bwd_weight_workspace(N, Cin, Cout, T, V, taps, stride)
     ws = torch.empty((nbytes + 3) // 4, dtype=torch.float32, device=x.device)
     dw = _empty(tuple(w_shape), x)
-    _lib.check(_L().agcn_conv_bwd_weight(_lib.ptr(dy), _lib.ptr(x), _lib.ptr(dw), _lib.ptr(ws), nbytes, N, Cin, Cout,
-                                         T, V, taps, stride, _lib.stream()), "agcn_conv_bwd_weight")
+    _lib.check(_L().agcn_conv_bwd_weight_ex(_lib.ptr(dy), _lib.ptr(x), _lib.ptr(dw), _lib.ptr(ws), nbytes, N, Cin, Cout,
+                                            T, V, taps, stride, _lib.ptr(dy_amax), _lib.ptr(x_amax), _lib.stream()),
+               "agcn_conv_bwd_weight")
     return dw
 
 
@@ -283,13 +286,14 @@ def fused_bwd_data_supported(C, Cout, V):
     return bool(_L().agcn_gcn_bwd_data_fused_supported(int(C), int(Cout), int(V)))
 
 
-def project_bwd_weight(dy, x, adj, Cout):
+def project_bwd_weight(dy, x, adj, Cout, dy_amax=None, x_amax=None):
     N, C, T, V = x.shape
     nbytes = _L().agcn_gcn_project_bwd_weight_workspace(N, C, Cout, T, V)
     ws = torch.empty((nbytes + 3) // 4, dtype=torch.float32, device=x.device)
     dw = _empty((Cout, 3 * C), x)
-    _lib.check(_L().agcn_gcn_project_bwd_weight(_lib.ptr(dy), _lib.ptr(x), _lib.ptr(adj), _lib.ptr(dw), _lib.ptr(ws),
-                                                nbytes, N, C, Cout, T, V, _lib.stream()),
+    _lib.check(_L().agcn_gcn_project_bwd_weight_ex(_lib.ptr(dy), _lib.ptr(x), _lib.ptr(adj), _lib.ptr(dw), _lib.ptr(ws),
+                                                   nbytes, N, C, Cout, T, V, _lib.ptr(dy_amax), _lib.ptr(x_amax),
+                                                   _lib.stream()),
                "agcn_gcn_project_bwd_weight")
     return dw
 
@@ -658,7 +662,8 @@ def gcn_forward(c, x, A, PA, wab, bab, wd, bd, bn, down, training, alpha=None, a
         # 3-channel first layer: aggregate+project and the `down` convolution in one pass over x (csrc/gcn_first.hip)
         ypre, st, dpre, st2 = gcn_first_fwd(x, adj, wd, bd, down[0], down[1], want_stats=training)
     else:
-        ypre, st = aggregate_project_fwd(x, adj, wd, bd, want_stats=training, x_amax=_take_out_amax(x))
+        c.g_x_amax = _take_out_amax(x)     # kept for the weight gradients of the backward
+        ypre, st = aggregate_project_fwd(x, adj, wd, bd, want_stats=training, x_amax=c.g_x_amax)
     bn2 = None
     if not first:
         dpre = None
@@ -691,12 +696,13 @@ def gcn_backward(c, dout, extra_add=None, extra_mask=None):
     dy_amax = _empty((1,), dout) if fused_amax_enabled() else None   # max |dypre| for the f16x3 backward-data chain
     dypre, dg1, db1, ddpre, dg2, db2 = bn_bwd(dout, c.g_bits, ypre, gamma1, c.g_bn1, dpre, gamma2, c.g_bn2,
                                               sync=c.g_sync, gcount=c.g_count, amax_out=dy_amax)
-    dwd = _side_run(lambda: project_bwd_weight(dypre, x, adj, Cout), (dypre, x, adj))
+    x_amax = getattr(c, 'g_x_amax', None)
+    dwd = _side_run(lambda: project_bwd_weight(dypre, x, adj, Cout, dy_amax, x_amax), (dypre, x, adj))
     dPA = dwab = dbab = dalpha = dtp = dtp_amax = None
     if c.g_adaptive:      # adjacency branch first: its dtp rides along in the dx kernel where that is supported
         dPA, dtp, dbab, dalpha, _, dtp_amax = adjacency_bwd(dypre, wd, x, tp, P, c.g_alpha, wab, c.g_bab,
                                                             dy_amax=dy_amax)
-        dwab = _side_run(lambda: conv_bwd_weight(dtp, x, wab.shape), (dtp, x))
+        dwab = _side_run(lambda: conv_bwd_weight(dtp, x, wab.shape, 1, dtp_amax, x_amax), (dtp, x))
     fuse = dtp is not None and fused_bwd_data_supported(x.shape[1], Cout, x.shape[3])
     ftp = dict(dtp=dtp, wab=wab) if fuse else {}
     ftp['dy_amax'] = dy_amax

@@ -109,6 +109,14 @@ int agcn_gcn_dadj_ex(const float* dy, const float* wcat, const float* x, float* 
                      size_t workspace_bytes, int N, int C, int Cout, int T, int V, const float* dy_absmax, void* stream);
 int agcn_adjacency_bwd_scores_ex(const float* tp, const float* dS, float* dtp, float* dbpart, void* scratch, float* db,
                                  float* dtp_absmax_out, int N, int Ci, int T, int V, void* stream);
+/* weight gradients: with BOTH operand maxima given the tap-free gradients (1x1, stride 1, Cin a multiple of 64; the
+ * projection gradient with C a multiple of 64) run on f16x3; NULL: bf16x6 as the plain entry points (no pass inside) */
+int agcn_conv_bwd_weight_ex(const float* dy, const float* x, float* dw, void* workspace, size_t workspace_bytes, int N,
+                            int Cin, int Cout, int T, int V, int taps, int stride, const float* dy_absmax,
+                            const float* x_absmax, void* stream);
+int agcn_gcn_project_bwd_weight_ex(const float* dy, const float* x, const float* adj, float* dwcat, void* workspace,
+                                   size_t workspace_bytes, int N, int C, int Cout, int T, int V, const float* dy_absmax,
+                                   const float* x_absmax, void* stream);
 int agcn_conv_fwd_ex(const float* x, const float* w, const float* bias, float* y, float* stats_part, void* workspace,
                      size_t workspace_bytes, int N, int Cin, int Cout, int T, int V, int taps, int stride,
                      const float* x_absmax, void* stream);
