@@ -544,3 +544,76 @@ def test_producer_consumer_kernels_are_bitwise_reproducible():
         else:
             for k, (a_, b_) in enumerate(zip(ref, cur)):
                 assert torch.equal(a_, b_), f'output {k} differs in repeat {rep}'
+
+
+# ---- f16x3 range scaling: the split-fp16 kernels multiply their streamed operand by a power of two taken from
+# the tensor's maximum, so operands far outside fp16's range (activations of 1e4, gradients of 1e-6) or spanning many
+# decades must come out as accurately as O(1) ones.  Errors here are measured against the fp64 result's own scale (not
+# max(1, .) as elsewhere in this file).  Maxima supplied by the caller (what the BatchNorm passes leave behind in the
+# product path) and maxima taken by the kernels' own pre-pass must give bit-identical results.
+def _rel_strict(a, ref):
+    a, ref = a.detach().double().cpu(), ref.detach().double().cpu()
+    return float((a - ref).abs().max() / ref.abs().max())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('case', [(1e4, 1e-6, False), (3e-5, 2e3, False), (1.0, 1.0, True), (7e4, 1e-7, True)])
+def test_f16x3_range_scaling(case):
+    from agcn_amd import ops, lib
+    dev = _gpu()
+    sx, sdy, wide = case
+    N, C, Cout, T, V = 2, 128, 128, 12, 25
+    g = torch.Generator().manual_seed(11)
+    x = rnd(g, N, C, T, V) * sx
+    dy = rnd(g, N, Cout, T, V) * sdy
+    if wide:     # seven decades inside one tensor: every other channel 1e-4 / 1e-7 of the rest
+        x[:, ::2] *= 1e-4
+        dy[:, 1::2] *= 1e-7
+    x.requires_grad_(True)
+    adj = rnd(g, N, 3, V, V, scale=0.3).requires_grad_(True)
+    wcat = rnd(g, Cout, 3 * C, scale=1.0 / np.sqrt(3 * C)).requires_grad_(True)
+    bias = rnd(g, Cout, scale=0.1 * sx)
+    y_ref = _gcn_ref(x, adj, wcat, bias)
+    y_ref.backward(dy)
+    xg, ag, wg, bg, dyg = [t.detach().float().to(dev) for t in (x, adj, wcat, bias, dy)]
+    x_amax, dy_amax = xg.abs().max().reshape(1), dyg.abs().max().reshape(1)
+    tol = 2e-5
+    y, _ = ops.aggregate_project_fwd(xg, ag, wg, bg)
+    assert _rel_strict(y, y_ref) < tol
+    y2, _ = ops.aggregate_project_fwd(xg, ag, wg, bg, x_amax=x_amax)
+    assert torch.equal(y, y2)
+    dx = ops.aggregate_project_bwd_data(dyg, ag, wg, tuple(x.shape))
+    assert _rel_strict(dx, x.grad) < tol
+    assert torch.equal(dx, ops.aggregate_project_bwd_data(dyg, ag, wg, tuple(x.shape), dy_amax=dy_amax))
+    # the fused 1x1 term shares the scale with dy: a dtp four decades above and below it
+    K2 = 6 * (Cout // 4)
+    wab = rnd(g, K2, C, scale=1.0 / np.sqrt(K2))
+    for sd in (1e4, 1e-4):
+        dtp = rnd(g, N, K2, T, V) * sdy * sd
+        ref = x.grad + torch.einsum('kc,nktv->nctv', wab, dtp)
+        dtpg = dtp.float().to(dev)
+        dx5 = ops.aggregate_project_bwd_data(dyg, ag, wg, tuple(x.shape), dtp=dtpg, wab=wab.float().to(dev).view(K2, C, 1, 1),
+                                             dy_amax=dy_amax, dtp_amax=dtpg.abs().max().reshape(1))
+        assert _rel_strict(dx5, ref) < tol
+    # weight gradients: bf16x6 without the maxima, f16x3 with both
+    for kw in ({}, dict(dy_amax=dy_amax, x_amax=x_amax)):
+        dw = ops.project_bwd_weight(dyg, xg, ag, Cout, **kw)
+        assert _rel_strict(dw, wcat.grad) < tol
+        dw1 = ops.conv_bwd_weight(dyg, xg, (Cout, C, 1, 1), **kw)
+        assert _rel_strict(dw1.view(Cout, C), torch.einsum('notv,nctv->oc', dy, x.detach())) < tol
+    # adjacency gradient
+    L = ops._L()
+    nslots = L.agcn_dadj_num_slots(C, V, T)
+    dpart = torch.empty((N, 3, nslots, V, V), device=dev)
+    ws, nb = ops._gcn_ws(C, Cout, T, V, xg)
+    lib.check(L.agcn_gcn_dadj_ex(lib.ptr(dyg), lib.ptr(wg), lib.ptr(xg), lib.ptr(dpart), ws.data_ptr(), nb, N, C, Cout, T,
+                                 V, lib.ptr(dy_amax), lib.stream()), 'dadj')
+    assert _rel_strict(dpart.sum(2), adj.grad) < tol
+    # temporal convolution (forward and backward-data run on f16x3 too)
+    w9 = rnd(g, Cout, C, 9, 1, scale=1.0 / np.sqrt(9 * C))
+    z_ref = torch.nn.functional.conv2d(x.detach(), w9, None, padding=(4, 0))
+    z, _ = ops.conv_fwd(xg, w9.float().to(dev), torch.zeros(Cout, device=dev), 1, x_amax=x_amax)
+    assert _rel_strict(z, z_ref) < tol
+    dz_ref = torch.nn.functional.conv_transpose2d(dy, w9, None, padding=(4, 0))
+    dz = ops.conv_bwd_data(dyg, w9.float().to(dev), tuple(x.shape), 1, dy_amax=dy_amax)
+    assert _rel_strict(dz, dz_ref) < tol
