@@ -310,7 +310,8 @@ scores_bwd_kernel(const float* __restrict__ tp, const float* __restrict__ dS, fl
               for (int e = 0; e < 4; ++e) {
                 val[e] = buf[cl * ttv + q + e];
                 sum += val[e];
-                mx = max(mx, __builtin_bit_cast(unsigned, val[e]) & 0x7fffffffu);
+                const float fv = val[e];
+                mx = max(mx, __float_as_uint(fv) & 0x7fffffffu);
               }
               *reinterpret_cast<f32x4_u*>(drow + q) = val;
             } else if (okr) {
@@ -320,7 +321,7 @@ scores_bwd_kernel(const float* __restrict__ tp, const float* __restrict__ dS, fl
                   const float val = buf[cl * ttv + q + e];
                   drow[q + e] = val;
                   sum += val;
-                  mx = max(mx, __builtin_bit_cast(unsigned, val) & 0x7fffffffu);
+                  mx = max(mx, __float_as_uint(val) & 0x7fffffffu);
                 }
             }
           }
@@ -353,7 +354,7 @@ scores_bwd_kernel(const float* __restrict__ tp, const float* __restrict__ dS, fl
           const int cl = r2 / tt, t_l = r2 - cl * tt;
           const bool ok = r2 < nrows && (c0 + cl) < Ci && t_l < tvalid;
           const float val = (ok && lr < V) ? d[j] : 0.f;
-          mx = max(mx, __builtin_bit_cast(unsigned, val) & 0x7fffffffu);
+          mx = max(mx, __float_as_uint(val) & 0x7fffffffu);
           if (ok && lr < V)
             dtp[(row0 + (long)which * Ci + c0 + cl) * P + (long)(t0 + t_l) * V + lr] = val;
           const float rs = half_sum(val);

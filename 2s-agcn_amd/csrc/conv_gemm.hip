@@ -20,6 +20,7 @@
 //   chunk k and committed to LDS after it, so HBM/L2 latency hides under the MFMAs; operand fragments are read one
 //   step ahead of the MFMAs that use them.
 #include "agcn_common.h"
+#include "split_f16.h"
 
 namespace {
 
@@ -558,6 +559,11 @@ const char* agcn_last_kernel(void) { return agcn_last_kernel_buf; }
 const char* agcn_gemm_mode(void) {
   const int m = agcn_gemm_precision();
   return m == 3 ? "bf16x6" : (m == 0 ? "f32" : (m == 1 ? "bf16" : "bf16x3"));
+}
+// *out = max |x| over n floats: the streaming pass the f16x3 kernels run themselves when no producer supplied the maximum
+int agcn_absmax(const float* x, long n, float* out, void* stream) {
+  if (!x || !out || n <= 0) return AGCN_ERR_ARG;
+  return agcn_launch_absmax(x, n, reinterpret_cast<unsigned*>(out), (hipStream_t)stream);
 }
 // arithmetic of unit_gcn's aggregate+project chain (forward and backward-data): "f16x3" in the default fp32-equivalent
 // mode (AGCN_CHAIN_F16X3=0: "bf16x6"), else AGCN_GEMM's mode

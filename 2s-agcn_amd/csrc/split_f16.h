@@ -52,11 +52,14 @@ static __global__ void __launch_bounds__(256) absmax_kernel(const float* __restr
   for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
     const f32x4 v = reinterpret_cast<const f32x4*>(xa)[i];
 #pragma unroll
-    for (int k = 0; k < 4; ++k) m = max(m, __builtin_bit_cast(unsigned, v[k]) & 0x7fffffffu);
+    for (int k = 0; k < 4; ++k) {          // (through a float: __builtin_bit_cast on a vector ELEMENT read element 0 four times)
+      const float f = v[k];
+      m = max(m, __float_as_uint(f) & 0x7fffffffu);
+    }
   }
   for (long i = (n4 << 2) + (long)blockIdx.x * 256 + threadIdx.x; i < na; i += (long)gridDim.x * 256)
-    m = max(m, __builtin_bit_cast(unsigned, xa[i]) & 0x7fffffffu);
-  if (blockIdx.x == 0 && (long)threadIdx.x < head) m = max(m, __builtin_bit_cast(unsigned, x[threadIdx.x]) & 0x7fffffffu);
+    m = max(m, __float_as_uint(xa[i]) & 0x7fffffffu);
+  if (blockIdx.x == 0 && (long)threadIdx.x < head) m = max(m, __float_as_uint(x[threadIdx.x]) & 0x7fffffffu);
 #pragma unroll
   for (int k = 32; k >= 1; k >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, k));
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;

@@ -44,6 +44,7 @@ SIGNATURES = {
     "agcn_adjacency_bwd_scores_ex": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
     "agcn_conv_bwd_weight_ex": (_I, [_P, _P, _P, _P, _Z, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P]),
     "agcn_gcn_project_bwd_weight_ex": (_I, [_P, _P, _P, _P, _P, _Z, _I, _I, _I, _I, _I, _P, _P, _P]),
+    "agcn_absmax": (_I, [_P, ctypes.c_long, _P, _P]),
     "agcn_bn_act_fwd_ex": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
     "agcn_bn_bwd_apply_ex": (_I, [_P, _I, _D, _F, _P, _P, _I] + [_P] * 16 + [_I, _I, _I, _P]),
     "agcn_conv_fwd_ex": (_I, [_P, _P, _P, _P, _P, _P, _Z, _I, _I, _I, _I, _I, _I, _I, _P, _P]),

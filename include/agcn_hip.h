@@ -117,6 +117,7 @@ int agcn_conv_bwd_weight_ex(const float* dy, const float* x, float* dw, void* wo
 int agcn_gcn_project_bwd_weight_ex(const float* dy, const float* x, const float* adj, float* dwcat, void* workspace,
                                    size_t workspace_bytes, int N, int C, int Cout, int T, int V, const float* dy_absmax,
                                    const float* x_absmax, void* stream);
+int agcn_absmax(const float* x, long n, float* out, void* stream);   /* *out = max |x|: the pass the f16x3 kernels run when given no maximum */
 int agcn_conv_fwd_ex(const float* x, const float* w, const float* bias, float* y, float* stats_part, void* workspace,
                      size_t workspace_bytes, int N, int Cin, int Cout, int T, int V, int taps, int stride,
                      const float* x_absmax, void* stream);

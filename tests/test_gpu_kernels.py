@@ -617,3 +617,20 @@ def test_f16x3_range_scaling(case):
     dz_ref = torch.nn.functional.conv_transpose2d(dy, w9, None, padding=(4, 0))
     dz = ops.conv_bwd_data(dyg, w9.float().to(dev), tuple(x.shape), 1, dy_amax=dy_amax)
     assert _rel_strict(dz, dz_ref) < tol
+
+
+@pytest.mark.gpu
+def test_absmax_pass_is_exact():
+    """agcn_absmax (the pass the f16x3 kernels run when no producer supplied the maximum) returns exactly max |x| for any
+    length and any 4-byte alignment (16-byte loads from the first aligned element, scalar head and tail)."""
+    from agcn_amd import ops, lib
+    dev = _gpu()
+    L = ops._L()
+    g = torch.Generator().manual_seed(3)
+    for n in (1, 3, 5, 1000, 76800, 76801, (1 << 20) + 3):
+        for off in (0, 1, 2, 3):
+            base = (torch.randn(n + 4, generator=g) * 1e-6).to(dev)
+            x = base[off:off + n]
+            out = torch.zeros(1, device=dev)
+            lib.check(L.agcn_absmax(x.data_ptr(), n, out.data_ptr(), lib.stream()), 'absmax')
+            assert float(out) == float(x.abs().max()), (n, off)
