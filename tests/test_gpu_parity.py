@@ -415,3 +415,41 @@ def test_inference_fold_matches_unfused_eval_and_takes_the_fused_path(monkeypatc
     err = float((out - ref).abs().max()) / scale
     assert err < 1e-4, err
     assert 'conv' in last and 'bn_' not in last, last
+
+
+def test_producer_emitted_maxima_equal_the_consumers_own_pass(monkeypatch):
+    """The f16x3 kernels scale their operands by the tensor maximum.  In the product path that maximum is a by-product of
+    the kernel that produced the tensor (BatchNorm passes, scores_bwd; AGCN_FUSED_AMAX=1, the default); with
+    AGCN_FUSED_AMAX=0 every consumer takes it with a pass of its own.  Both must see the SAME maximum: the logits and the
+    input gradient of a training step (which only depend on forward / backward-data kernels) agree bit for bit; the
+    parameter gradients agree to fp32 accuracy (without the maxima the tap-free weight gradients stay on bf16x6).
+    All nine unit inputs l2..l10 find their maximum left behind (ops._OUT_AMAX_STATS)."""
+    from agcn_amd import ops
+    from agcn_amd.model import agcn as magcn
+    dev = torch.device('cuda:0')
+    torch.manual_seed(3)
+    model = magcn.Model(num_class=60, num_point=25, num_person=2, graph='graph.ntu_rgb_d.Graph',
+                        graph_args={'labeling_mode': 'spatial'}).to(dev).train()
+    g = torch.Generator().manual_seed(9)
+    x0 = torch.randn(2, 3, 32, 25, 2, generator=g).to(dev)
+    res = {}
+    for mode in ('1', '0'):
+        monkeypatch.setenv('AGCN_FUSED_AMAX', mode)
+        model.zero_grad(set_to_none=True)
+        x = x0.clone().requires_grad_(True)
+        before = list(ops._OUT_AMAX_STATS)
+        logits = model(x)
+        logits.logsumexp(1).sum().backward()
+        torch.cuda.synchronize()
+        hits = [a - b for a, b in zip(ops._OUT_AMAX_STATS, before)]
+        res[mode] = (logits.detach().clone(), x.grad.clone(),
+                     {n: p.grad.clone() for n, p in model.named_parameters() if p.grad is not None}, hits)
+    assert res['1'][3] == [0, 9], res['1'][3]            # [misses, hits]
+    assert torch.equal(res['1'][0], res['0'][0])
+    assert torch.equal(res['1'][1], res['0'][1])
+    worst = 0.0
+    for n, ga in res['1'][2].items():
+        gb = res['0'][2][n]
+        worst = max(worst, float((ga - gb).abs().max()) / max(1e-12, float(gb.abs().max())))
+    assert worst < 2e-4, worst
+    print(f'producer-emitted maxima: logits / dx bit-identical, worst parameter-gradient difference {worst:.2e}')
