@@ -72,3 +72,11 @@ def allreduce_scalar(value, world_size, device):
     if world_size > 1:
         dist.all_reduce(t, op=dist.ReduceOp.SUM)
     return float(t.item())
+
+
+def allreduce_min_flag(flag, world_size, device):
+    """True only if ``flag`` holds on EVERY rank (one tiny MIN all-reduce; used once, to agree on a static schedule)."""
+    t = torch.tensor([1.0 if flag else 0.0], dtype=torch.float32, device=device)
+    if world_size > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MIN)
+    return bool(t.item() > 0.5)

@@ -166,6 +166,11 @@ class TCN_GCN_unit(nn.Module):
             self.residual = unit_tcn(in_channels, out_channels, kernel_size=1, stride=stride)
             self.res_mode = 2
 
+    def train(self, mode=True):
+        # folded inference weights are derived from parameters the training path rewrites in place
+        self.__dict__.pop('_infer_cache', None)
+        return super().train(mode)
+
     def forward(self, x):
         _require_gpu(x, 'TCN_GCN_unit')
         t = self.tcn1

@@ -620,6 +620,7 @@ def _bn_coeffs(training, stats, count, bns, sync=None, nsamples=None):
     if sync is not None:
         stats = sync_stats(stats, count, sync)
         count = count * sync.world
+    note_params_changed()                             # running statistics are about to be rewritten in place
     res = [bn_train_coeffs(sp, count, *bn) for sp, bn in zip(stats, bns)]
     for st in res:
         st.S = S
@@ -776,6 +777,16 @@ def tcn_backward(c, dout, join=True):
 # ---- BN-folded inference (eval mode under no_grad): adjacency + two kernels per TCN_GCN_unit ----------------------
 ERR_UNSUPPORTED = -3
 
+# Parameters and BatchNorm running statistics are written through RAW POINTERS by the training path (agcn_sgd_step on the
+# flat buffer, agcn_bn_stats_finalize), which moves neither data_ptr nor the tensors' version counters.  Everything that
+# caches something derived from them (the folded inference weights) keys on this counter too; it is bumped by every
+# optimiser step and every training-mode BatchNorm stage.
+_PARAM_EPOCH = [0]
+
+
+def note_params_changed():
+    _PARAM_EPOCH[0] += 1
+
 
 def infer_fold_enabled():
     """AGCN_INFER_FOLD=0 keeps the eval forward on the unfused passes (A/B and debugging)."""
@@ -836,7 +847,7 @@ def unit_infer(x, A, PA, wab, bab, wd, bd, gbn, down, tw, tb, tbn, res_mode, res
         return None
     srcs = [wd, bd, *gbn, tw, tb, *tbn] + (list(down) if down is not None else []) + \
            (list(res) if isinstance(res, tuple) else [])
-    key = tuple((t.data_ptr(), t._version) for t in srcs)
+    key = (_PARAM_EPOCH[0],) + tuple((t.data_ptr(), t._version) for t in srcs)
     f = cache.get('folded') if cache is not None else None
     if f is None or f[0] != key:
         s1, sh1 = _fold(gbn)

@@ -137,6 +137,24 @@ class NpyFeeder(torch.utils.data.Dataset):
         return np.asarray(self.data[i], dtype=np.float32), self.label[i], i
 
 
+def use_device_augment(Feeder, feeder_kwargs, flag):
+    """Whether the feeder's transforms run batch-wise on the GPU (feeders.DeviceAugment) for this configuration.
+    DeviceAugment implements neither ``stretch`` nor ``random_subsample`` (reference feeders/feeder.py:184-185, 206-208):
+    a config that asks for one of them keeps ALL transforms on the host, in the reference's order, instead of silently
+    training on different data."""
+    if not (bool(flag) and hasattr(Feeder, 'rotation_theta')):
+        return False
+    return not (feeder_kwargs.get('stretch') or feeder_kwargs.get('random_subsample') is not None)
+
+
+def prepare_batch(data, aug):
+    """What BOTH phases feed the model: the batch as float32 with the feeder's (device-side) transforms applied.  The
+    reference applies normalization / window padding / ... in ``__getitem__`` whatever the phase (feeder.py:182-221);
+    with device_augment the feeder returns raw clips and the same transforms live in ``aug``."""
+    data = data.float()
+    return aug(data) if aug is not None else data
+
+
 class _IndexSampler(torch.utils.data.Sampler):
     """Yields the index list it currently holds (set per epoch by ``Processor._loader``)."""
 
@@ -233,7 +251,7 @@ class Processor:
 
         def build(kwargs, train):
             kw = dict(kwargs)
-            dev_aug = bool(self.arg.device_augment) and hasattr(Feeder, 'rotation_theta')
+            dev_aug = use_device_augment(Feeder, kw, self.arg.device_augment)
             if dev_aug:
                 kw['device_augment'] = True
             ds = Feeder(**kw)
@@ -294,9 +312,7 @@ class Processor:
             return dt
         for step, (data, label, _) in enumerate(loader):
             timer['dataloader'] += split()
-            data = data.float()
-            if aug is not None:
-                data = aug(data)
+            data = prepare_batch(data, aug)
             if freeze_pa:
                 loss = self._train_step_frozen_pa(data, label)
             else:
@@ -346,10 +362,13 @@ class Processor:
         self.model.eval()
         loader, idx = self._loader(loader_name, epoch)
         ds = self.datasets[loader_name]
+        # the feeder's transforms run in BOTH phases (reference feeder.py:182-221: normalization, window_size padding
+        # ... are applied by __getitem__ whatever the phase); with device_augment they live in DeviceAugment
+        aug = self.augment.get(loader_name)
         scores, loss_sum, seen = [], 0.0, 0
         with torch.no_grad():
             for data, label, _ in loader:
-                out = self.model(data.float())
+                out = self.model(prepare_batch(data, aug))
                 out = out[0] if isinstance(out, tuple) else out
                 loss_sum += float(torch.nn.functional.cross_entropy(out, label, reduction='sum'))
                 seen += label.numel()

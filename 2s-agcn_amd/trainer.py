@@ -105,6 +105,8 @@ class TrainEngine:
         self.norm = torch.zeros(2, dtype=torch.float32, device=dev)
         self.loss_fn = torch.nn.CrossEntropyLoss()
         self._tail_lo = None          # first parameter index of the early all-reduce bucket (world_size > 1)
+        self._tail_static = None      # None: undecided (first step only probes); True / False: agreed by ALL ranks
+        self._tail_probe = False      # what this rank's hook saw during the probing step
         self._pending = []            # async all-reduce handles of this step
         self.early_buckets = 0        # how many steps sent their tail bucket from inside the backward (diagnostic)
         if world_size > 1:
@@ -138,13 +140,28 @@ class TrainEngine:
         (AccumulateGrad nodes run at top priority).  If one is missing anyway, the bucket simply waits for the end."""
         if self._tail_lo is None or self._pending:
             return None
-        if self.fp.gather_grads(self._tail_lo, None, require_all=True):
-            off = self.fp.offsets[self._tail_lo]
-            self._pending.append(_dp.allreduce_gradients(self.fp.grad[off:], self.world_size, async_op=True))
-            self.early_buckets += 1
+        # The bucket schedule must be IDENTICAL on every rank (ranks issuing tail+head against ranks issuing one full
+        # all-reduce would hang or mix buffers), so it is decided once: the first step only probes whether the tail is
+        # complete when the hook fires, the ranks agree on the answer (MIN all-reduce in _finish_allreduce), and from
+        # then on the schedule is static -- a rank that cannot honour it raises instead of silently deviating.
+        if self._tail_static is None:
+            self._tail_probe = all(p.grad is not None for p in self.fp.params[self._tail_lo:])
+            return None
+        if not self._tail_static:
+            return None
+        if not self.fp.gather_grads(self._tail_lo, None, require_all=True):
+            raise RuntimeError("agcn_amd.TrainEngine: a parameter behind the all-reduce cut had no gradient when the "
+                               "backward passed the cut module, although all ranks agreed on the two-bucket schedule "
+                               "at the first step; the schedule is static (every rank must issue the same collectives)")
+        off = self.fp.offsets[self._tail_lo]
+        self._pending.append(_dp.allreduce_gradients(self.fp.grad[off:], self.world_size, async_op=True))
+        self.early_buckets += 1
         return None
 
     def _finish_allreduce(self):
+        if self._tail_lo is not None and self._tail_static is None:
+            # first step: agree on the schedule (every rank must see its tail complete at the cut)
+            self._tail_static = bool(_dp.allreduce_min_flag(self._tail_probe, self.world_size, self.fp.grad.device))
         if self._pending:             # tail bucket already in flight: only the head remains
             off = self.fp.offsets[self._tail_lo]
             self.fp.gather_grads(0, self._tail_lo)
@@ -192,6 +209,8 @@ class TrainEngine:
                                    int(self.steps_done == 0), self.ws.data_ptr(), self.ws.numel() * 4,
                                    self.norm.data_ptr(), _lib.stream()), "agcn_sgd_step")
         self.steps_done += 1
+        from . import ops as _ops
+        _ops.note_params_changed()        # raw-pointer update: invalidates caches derived from the parameters
 
     def grad_norm(self):
         return float(self.norm[0])

@@ -163,3 +163,35 @@ def test_gpu_feeders_device_loader_and_augment(tmp_path):
         assert torch.allclose(y.cpu().double(), y_cpu, atol=1e-5)
         seen += 4
     assert seen == 16
+
+
+def test_eval_input_equals_host_feeder_output_with_normalization_and_window(tmp_path):
+    """With device_augment the feeder returns RAW clips; what Processor.train AND Processor.eval feed the model
+    (processor.prepare_batch) must equal what the host feeder's __getitem__ returns -- the deterministic transforms
+    (normalization, window_size padding) apply in both phases (reference feeder.py:182-221)."""
+    from agcn_amd.processor import prepare_batch, use_device_augment
+    _dataset(tmp_path)
+    kw = dict(data_path=str(tmp_path / 'data.npy'), label_path=str(tmp_path / 'label.pkl'), window_size=24,
+              normalization=True)
+    host = Feeder(**kw)
+    assert use_device_augment(Feeder, kw, True)
+    dev = Feeder(device_augment=True, **kw)
+    aug = DeviceAugment.from_feeder(dev)
+    idx = [0, 3, 7]
+    raw = torch.from_numpy(np.stack([dev[i][0] for i in idx]))
+    want = np.stack([host[i][0] for i in idx])
+    assert raw.shape[2] == 20 and want.shape[2] == 24                  # raw clips are neither padded nor normalised
+    got = prepare_batch(raw, aug).numpy()
+    assert got.shape == want.shape and np.allclose(got, want, atol=1e-5)
+    assert prepare_batch(raw, None) is not None and prepare_batch(raw.double(), None).dtype == torch.float32
+
+
+def test_transforms_missing_on_the_device_keep_the_host_path():
+    """stretch / random_subsample exist only as host transforms: such a config must not lose them silently."""
+    from agcn_amd.processor import use_device_augment
+    assert use_device_augment(Feeder, dict(random_move=True, window_size=150, random_choose=True), True)
+    assert not use_device_augment(Feeder, dict(random_subsample=60), True)
+    assert not use_device_augment(Feeder, dict(stretch=True), True)
+    assert use_device_augment(Feeder, dict(stretch=False, random_subsample=None), True)
+    assert not use_device_augment(Feeder, dict(), False)
+    assert not use_device_augment(object, dict(), True)               # feeders without the device protocol

@@ -389,7 +389,7 @@ def test_inference_fold_matches_unfused_eval_and_takes_the_fused_path(monkeypatc
     import agcn_amd
     from agcn_amd import lib, ops
     from agcn_amd.model import agcn as magcn
-    dev = torch.device('cuda:0')
+    dev = _gpu()
     torch.manual_seed(11)
     model = magcn.Model(num_class=60, num_point=25, num_person=2, graph='graph.ntu_rgb_d.Graph',
                         graph_args={'labeling_mode': 'spatial'}).to(dev)
@@ -417,6 +417,49 @@ def test_inference_fold_matches_unfused_eval_and_takes_the_fused_path(monkeypatc
     assert 'conv' in last and 'bn_' not in last, last
 
 
+def test_inference_fold_follows_training(monkeypatch):
+    """The folded inference weights are derived from parameters and running statistics that the training path rewrites
+    IN PLACE through raw pointers (agcn_sgd_step, agcn_bn_stats_finalize): neither data_ptr nor the version counters
+    move.  eval -> a few train steps -> eval must see the NEW weights: compared against the unfused eval passes."""
+    dev = _gpu()
+    from agcn_amd.model import agcn as magcn
+    from agcn_amd.trainer import TrainEngine
+    torch.manual_seed(21)
+    model = magcn.Model(num_class=60, num_point=25, num_person=2, graph='graph.ntu_rgb_d.Graph',
+                        graph_args={'labeling_mode': 'spatial'}).to(dev)
+    g = torch.Generator().manual_seed(6)
+    with torch.no_grad():
+        for n, p in model.named_parameters():
+            if n.endswith('gcn1.bn.weight'):
+                p.copy_((0.5 + torch.rand(p.shape, generator=g)).to(dev))
+    eng = TrainEngine(model, base_lr=0.1)
+    x = torch.randn(4, 3, 40, 25, 2, generator=g).to(dev)
+    y = torch.randint(0, 60, (4,), generator=g).to(dev)
+
+    def evals():
+        model.eval()
+        with torch.no_grad():
+            monkeypatch.setenv('AGCN_INFER_FOLD', '1')
+            a = model(x).clone()
+            monkeypatch.setenv('AGCN_INFER_FOLD', '0')
+            b = model(x).clone()
+            monkeypatch.setenv('AGCN_INFER_FOLD', '1')
+        return a, b
+    a0, b0 = evals()
+    assert float((a0 - b0).abs().max()) <= 1e-4 * max(1.0, float(b0.abs().max()))
+    for _ in range(3):
+        eng.train_step(x, y)
+    a1, b1 = evals()
+    scale = max(1.0, float(b1.abs().max()))
+    assert float((b1 - b0).abs().max()) > 1e-3 * scale          # the weights really moved
+    assert float((a1 - b1).abs().max()) <= 1e-4 * scale, float((a1 - b1).abs().max())
+    # and again WITHOUT leaving eval mode in between (the optimiser step alone must invalidate the cache)
+    model.eval()
+    eng.apply_update()
+    a2, b2 = evals()
+    assert float((a2 - b2).abs().max()) <= 1e-4 * max(1.0, float(b2.abs().max()))
+
+
 def test_producer_emitted_maxima_equal_the_consumers_own_pass(monkeypatch):
     """The f16x3 kernels scale their operands by the tensor maximum.  In the product path that maximum is a by-product of
     the kernel that produced the tensor (BatchNorm passes, scores_bwd; AGCN_FUSED_AMAX=1, the default); with
@@ -426,7 +469,7 @@ def test_producer_emitted_maxima_equal_the_consumers_own_pass(monkeypatch):
     All nine unit inputs l2..l10 find their maximum left behind (ops._OUT_AMAX_STATS)."""
     from agcn_amd import ops
     from agcn_amd.model import agcn as magcn
-    dev = torch.device('cuda:0')
+    dev = _gpu()
     torch.manual_seed(3)
     model = magcn.Model(num_class=60, num_point=25, num_person=2, graph='graph.ntu_rgb_d.Graph',
                         graph_args={'labeling_mode': 'spatial'}).to(dev).train()
