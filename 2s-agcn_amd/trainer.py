@@ -90,7 +90,9 @@ def learning_rate(epoch, base_lr, steps, warm_up_epoch=0):
 
 class TrainEngine:
     def __init__(self, model, base_lr=0.1, momentum=0.9, nesterov=True, weight_decay=1e-4, max_grad_norm=1.0,
-                 world_size=1):
+                 world_size=1, tail_bucket='auto'):
+        """tail_bucket: 'auto' = the first step probes whether the early (tail) all-reduce bucket is possible and the
+        ranks agree on it; True / False = fixed from the start (must be the same on every rank)."""
         self.model = model
         self.fp = FlatParams(model)
         self.lr = base_lr
@@ -111,6 +113,8 @@ class TrainEngine:
         self.early_buckets = 0        # how many steps sent their tail bucket from inside the backward (diagnostic)
         if world_size > 1:
             self._setup_overlap()
+            if tail_bucket != 'auto':
+                self._tail_static = bool(tail_bucket) and self._tail_lo is not None
 
     # ---- gradient all-reduce overlapped with the backward -----------------------------------------------------------
     def _setup_overlap(self):

@@ -68,7 +68,7 @@ def worker(mode):
     m = _build(dev)
     if mode == 'sync':
         m = dp.enable_sync_bn(m, world)
-    eng = TrainEngine(m, world_size=world, **kw)
+    eng = TrainEngine(m, world_size=world, tail_bucket=True, **kw)     # static two-bucket schedule from step 1
     dp.broadcast_parameters(eng.fp.flat, world)
     p0 = eng.fp.flat.clone()
     eng.train_step(x[rank::world], y[rank::world])
