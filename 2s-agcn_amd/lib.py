@@ -79,6 +79,16 @@ SIGNATURES = {
     "agcn_stc_row_reduce": (_I, [_P, _P, _P, _P, _I, _P, _P, _F, _F, _I, _I, _I, _I, _P]),
     "agcn_stc_apply": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
     "agcn_stc_bwd_apply": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
+    "agcn_data_bn_stats": (_I, [_P, _P, _I, _I, _I, _I, _I, _P]),
+    "agcn_data_bn_apply": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
+    "agcn_data_bn_bwd_reduce": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
+    "agcn_data_bn_bwd_apply": (_I, [_P, _P, _P, _P, _P, _P, _D, _P, _I, _I, _I, _I, _I, _P]),
+    "agcn_pool_fwd": (_I, [_P, _P, _P, _I, _I, _I, _I, _P]),
+    "agcn_pool_bwd": (_I, [_P, _P, _I, _I, _I, _I, _P]),
+    "agcn_linear_fwd": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _P]),
+    "agcn_linear_bwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
+    "agcn_gate_conv_fwd": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _P]),
+    "agcn_gate_conv_bwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
     "agcn_sgd_step_workspace": (_Z, [ctypes.c_long]),
     "agcn_sgd_step": (_I, [_P, _P, _P, ctypes.c_long, _F, _F, _F, _I, _F, _F, _I, _P, _Z, _P, _P]),
 }

@@ -24,7 +24,8 @@ import torch
 import torch.nn as nn
 
 from .. import ops
-from .agcn import _bn_args, _bn_tick, _require_gpu, bn_init, conv_branch_init, conv_init, import_class
+from .agcn import (_bn_args, _bn_tick, _require_gpu, bn_init, conv_branch_init, conv_init, data_bn_forward,
+                   import_class)
 from .ghostbatchnorm import GhostBatchNorm1d, GhostBatchNorm2d
 
 
@@ -312,11 +313,8 @@ class BaseModel(nn.Module):
         nn.init.normal_(self.fc.weight, 0, math.sqrt(2. / out_channels))
 
     def forward_preprocess(self, x, size):
-        N, C, T, V, M = size
-        x = x.permute(0, 4, 3, 1, 2).contiguous().view(N, -1, T)
-        x = self.data_bn(x)
-        x = x.view(N, M, V, C, T).permute(0, 1, 3, 4, 2).contiguous()
-        return x.view(-1, C, T, V)
+        _require_gpu(x, 'aagcn.Model')
+        return data_bn_forward(self.data_bn, x)
 
     def forward_model_backbone(self, x, size):
         for k in range(1, 11):
@@ -326,13 +324,22 @@ class BaseModel(nn.Module):
     def forward_postprocess(self, x, size):
         N, C, T, V, M = size
         c_new = x.size(1)
+        if self._fused_head():
+            return x, None                    # pooled inside forward_classifier (one autograd node with the Linear)
         if self.fc_cv:
             x = x.view(N, M, c_new, -1, V).mean(3).mean(1).view(N, -1)
         else:
             x = x.view(N, M, c_new, -1).mean(3).mean(1)
         return x, None
 
+    def _fused_head(self):
+        """global average pool + Linear on the deterministic HIP kernels (ops.PoolFCFunction): the default head (no
+        fc_cv, no dropout) on a backbone that ends in a unit."""
+        return (not self.fc_cv) and not isinstance(self.drop_out, nn.Dropout) and isinstance(self.fc, nn.Linear)
+
     def forward_classifier(self, x, size):
+        if self._fused_head() and x.dim() == 4:
+            return ops.PoolFCFunction.apply(x, self.fc.weight, self.fc.bias, size[4])
         return self.fc(self.drop_out(x))
 
     def forward(self, x):

@@ -61,6 +61,21 @@ def _bn_tick(bn, training):
         bn.num_batches_tracked.add_(1)
 
 
+def data_bn_forward(bn, x):
+    """Model prologue: (N, C, T, V, M) -> BatchNorm1d over channels (m, v, c) -> (N*M, C, T, V) (reference
+    agcn.py:163-165) on the deterministic HIP kernels; modules other than plain / synchronised BatchNorm1d (GhostBatchNorm1d)
+    keep their own forward."""
+    N, C, T, V, M = x.size()
+    if ops.data_bn_supported(bn):
+        y = ops.DataBNFunction.apply(x, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.training,
+                                     ops.sync_of(bn))
+        _bn_tick(bn, bn.training)
+        return y
+    x = x.permute(0, 4, 3, 1, 2).contiguous().view(N, M * V * C, T)
+    x = bn(x)
+    return x.view(N, M, V, C, T).permute(0, 1, 3, 4, 2).contiguous().view(N * M, C, T, V)
+
+
 class unit_tcn(nn.Module):
     def __init__(self, in_channels, out_channels, kernel_size=9, stride=1):
         super().__init__()
@@ -222,12 +237,9 @@ class Model(nn.Module):
 
     def forward(self, x):
         N, C, T, V, M = x.size()
-        x = x.permute(0, 4, 3, 1, 2).contiguous().view(N, M * V * C, T)
-        x = self.data_bn(x)
-        x = x.view(N, M, V, C, T).permute(0, 1, 3, 4, 2).contiguous().view(N * M, C, T, V)
+        _require_gpu(x, 'Model')
+        x = data_bn_forward(self.data_bn, x)            # (N*M, C, T, V), reference agcn.py:163-165
         for k in range(1, 11):
             x = getattr(self, f'l{k}')(x)
-        c_new = x.size(1)
-        x = x.view(N, M, c_new, -1)
-        x = x.mean(3).mean(1)
-        return self.fc(x)
+        # global average pool over (T, V), then persons, and the classifier (agcn.py:179-183)
+        return ops.PoolFCFunction.apply(x, self.fc.weight, self.fc.bias, M)

@@ -353,27 +353,165 @@ def stc_row_reduce(y, g=None, wv=None, wt=None, want_t=False, want_v=False, scal
     return out_t, out_v
 
 
+# ---- the small operators around the unit stack (csrc/small_ops.hip): deterministic, no vendor library --------------
+def linear_fwd(x, w, b, act=0):
+    """out = act(x @ w.T + b); act 0 identity, 1 ReLU, 2 "1 + sigmoid".  x (N, K), w (O, K)."""
+    N, K = x.shape
+    O = w.shape[0]
+    out = _empty((N, O), x)
+    _lib.check(_L().agcn_linear_fwd(_lib.ptr(x), _lib.ptr(w), _lib.ptr(b), _lib.ptr(out), N, K, O, int(act),
+                                    _lib.stream()), "agcn_linear_fwd")
+    return out
+
+
+def linear_bwd(dout, out, x, w, act=0, need_din=True):
+    """Returns din (or None), dw, db of linear_fwd."""
+    N, K = x.shape
+    O = w.shape[0]
+    dpre = _empty((N, O), x)
+    din = _empty((N, K), x) if need_din else None
+    dw, db = _empty((O, K), x), _empty((O,), x)
+    _lib.check(_L().agcn_linear_bwd(_lib.ptr(dout), _lib.ptr(out), _lib.ptr(x), _lib.ptr(w), _lib.ptr(dpre),
+                                    _lib.ptr(din), _lib.ptr(dw), _lib.ptr(db), N, K, O, int(act), _lib.stream()),
+               "agcn_linear_bwd")
+    return din, dw, db
+
+
+def gate_conv_fwd(x, w, b):
+    """a (N, L) = 1 + sigmoid(Conv1d(C -> 1, Ks, padding (Ks-1)/2)(x)); x (N, C, L), w (1, C, Ks), b (1)."""
+    N, C, L = x.shape
+    Ks = w.shape[-1]
+    a = _empty((N, L), x)
+    _lib.check(_L().agcn_gate_conv_fwd(_lib.ptr(x), _lib.ptr(w.reshape(C, Ks)), _lib.ptr(b), _lib.ptr(a), N, C, L, Ks,
+                                       _lib.stream()), "agcn_gate_conv_fwd")
+    return a
+
+
+def gate_conv_bwd(da, a, x, w):
+    """Returns dx (N, C, L), dw (1, C, Ks), db (1) of gate_conv_fwd given da = dL/da."""
+    N, C, L = x.shape
+    Ks = w.shape[-1]
+    dpre = _empty((N, L), x)
+    dx, dw, db = _empty((N, C, L), x), _empty((1, C, Ks), x), _empty((1,), x)
+    _lib.check(_L().agcn_gate_conv_bwd(_lib.ptr(da), _lib.ptr(a), _lib.ptr(x), _lib.ptr(w.reshape(C, Ks)),
+                                       _lib.ptr(dpre), _lib.ptr(dx), _lib.ptr(dw), _lib.ptr(db), N, C, L, Ks,
+                                       _lib.stream()), "agcn_gate_conv_bwd")
+    return dx, dw, db
+
+
+class DataBNFunction(torch.autograd.Function):
+    """The model prologue (reference agcn.py:163-165): x (N, C, T, V, M) -> permute/view (N, M*V*C, T) -> BatchNorm1d ->
+    view/permute -> (N*M, C, T, V), as three small deterministic kernels (statistics, finalize, apply).
+    args: x, weight, bias, running_mean, running_var, training, sync"""
+
+    @staticmethod
+    def forward(ctx, x, w, b, rm, rv, training, sync=None):
+        x = x.contiguous()
+        N, C, T, V, M = x.shape
+        CH = C * V * M
+        L = _L()
+        if training:
+            part = _empty((N, 2, CH), x)
+            _lib.check(L.agcn_data_bn_stats(_lib.ptr(x), _lib.ptr(part), N, C, T, V, M, _lib.stream()),
+                       "agcn_data_bn_stats")
+            (st,), gcount = _bn_coeffs(True, [part], N * T, [(w, b, rm, rv)], sync, N)
+        else:
+            (st,), gcount = _bn_coeffs(False, [None], N * T, [(w, b, rm, rv)], None, N)
+        out = _empty((N * M, C, T, V), x)
+        _lib.check(L.agcn_data_bn_apply(_lib.ptr(x), _lib.ptr(st.scale), _lib.ptr(st.shift), _lib.ptr(out), N, C, T, V, M,
+                                        _lib.stream()), "agcn_data_bn_apply")
+        ctx.st, ctx.sync, ctx.gcount, ctx.training = st, sync, gcount, training
+        ctx.save_for_backward(x, w)
+        return out
+
+    @staticmethod
+    def backward(ctx, dy):
+        _need_train(ctx.training)
+        x, w = ctx.saved_tensors
+        st, sync = ctx.st, ctx.sync
+        dy = dy.contiguous()
+        N, C, T, V, M = x.shape
+        CH = C * V * M
+        L = _L()
+        part = _empty((N, 2, CH), x)
+        _lib.check(L.agcn_data_bn_bwd_reduce(_lib.ptr(dy), _lib.ptr(x), _lib.ptr(st.mean), _lib.ptr(st.invstd),
+                                             _lib.ptr(part), N, C, T, V, M, _lib.stream()), "agcn_data_bn_bwd_reduce")
+        sums = _colsum(part, N, 2 * CH)
+        scale = 1.0
+        if sync is not None:
+            sums = _allreduce_sum(sums, sync)
+            scale = 1.0 / sync.world       # global sums, restored by the gradient average of the data-parallel step
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty_like(x)
+            _lib.check(L.agcn_data_bn_bwd_apply(_lib.ptr(dy), _lib.ptr(x), _lib.ptr(w), _lib.ptr(st.mean),
+                                                _lib.ptr(st.invstd), _lib.ptr(sums), float(ctx.gcount), _lib.ptr(dx), N, C,
+                                                T, V, M, _lib.stream()), "agcn_data_bn_bwd_apply")
+        dbeta, dgamma = sums[:CH], sums[CH:]
+        if scale != 1.0:
+            dbeta, dgamma = dbeta * scale, dgamma * scale
+        return dx, dgamma, dbeta, None, None, None, None
+
+
+def data_bn_supported(bn):
+    """Plain / synchronised BatchNorm1d only (GhostBatchNorm1d keeps its own module path)."""
+    return type(bn) in (torch.nn.BatchNorm1d, torch.nn.SyncBatchNorm)
+
+
+class PoolFCFunction(torch.autograd.Function):
+    """The model epilogue (reference agcn.py:179-183): mean over (T, V) per person, mean over persons, Linear.
+    args: x (N*M, C, T, V), fc weight (K, C), fc bias (K), M"""
+
+    @staticmethod
+    def forward(ctx, x, w, b, M):
+        x = x.contiguous()
+        NM, C, T, V = x.shape
+        N = NM // M
+        rowmean, pooled = _empty((NM, C), x), _empty((N, C), x)
+        _lib.check(_L().agcn_pool_fwd(_lib.ptr(x), _lib.ptr(rowmean), _lib.ptr(pooled), N, M, C, T * V, _lib.stream()),
+                   "agcn_pool_fwd")
+        logits = linear_fwd(pooled, w, b, 0)
+        ctx.save_for_backward(pooled, logits, w)
+        ctx.shape, ctx.M = (NM, C, T, V), M
+        return logits
+
+    @staticmethod
+    def backward(ctx, dlogits):
+        pooled, logits, w = ctx.saved_tensors
+        NM, C, T, V = ctx.shape
+        M = ctx.M
+        dpooled, dw, db = linear_bwd(dlogits.contiguous(), logits, pooled, w, 0, need_din=True)
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = _empty((NM, C, T, V), pooled)
+            _lib.check(_L().agcn_pool_bwd(_lib.ptr(dpooled), _lib.ptr(dx), NM // M, M, C, T * V, _lib.stream()),
+                       "agcn_pool_bwd")
+        return dx, dw, db, None
+
+
 class STCAttentionFunction(torch.autograd.Function):
     """AAGCN's three attention gates (reference aagcn.py:59-116 applied at :268-270) as ONE autograd node:
         y3 = y * (1+se_s[n,v]) * (1+se_t[n,t]) * (1+se_c[n,c])
     Full-tensor work = HIP passes (forward: two reductions + one apply = 3 reads, 1 write of the activation; backward:
     one pass over (dout, y), one over y, one apply = 4 reads, 1 write); the gate networks (Conv1d C->1 over joints /
     frames, two Linears) act on (N,C,V) / (N,C,T) / (N,C) tensors and run as ordinary tensor code, differentiated by
-    autograd on those small tensors inside ``backward``.
+    explicit small kernels too (gate_conv_* / linear_* above).
     args: y, sa_w (1,C,Ks), sa_b (1), ta_w (1,C,9), ta_b (1), fc1_w, fc1_b, fc2_w, fc2_b"""
 
     @staticmethod
     def _gates(m_s, mv1, sa_w, sa_b, ta_w, ta_b, f1w, f1b, f2w, f2b, a_s=None):
-        """a_s (N,V) from mean_t y; a_t (N,T) from mean_v y1; a_c (N,C) from mean_t(a_t * mean_v y1)."""
-        F = torch.nn.functional
+        """a_s (N,V) from mean_t y; a_t (N,T) from mean_v y1; a_c (N,C) from mean_t(a_t * mean_v y1).  The gate
+        networks are the deterministic kernels of csrc/small_ops.hip (gate convolution, small Linear).
+        Returns (a_s, a_t, a_c, m_c, h) with m_c / h the channel gate's input and hidden activations."""
         if a_s is None:
-            a_s = 1.0 + torch.sigmoid(F.conv1d(m_s, sa_w, sa_b, padding=(sa_w.shape[-1] - 1) // 2)).squeeze(1)
+            a_s = gate_conv_fwd(m_s, sa_w, sa_b)
         if mv1 is None:
-            return a_s, None, None
-        a_t = 1.0 + torch.sigmoid(F.conv1d(mv1, ta_w, ta_b, padding=(ta_w.shape[-1] - 1) // 2)).squeeze(1)
+            return a_s, None, None, None, None
+        a_t = gate_conv_fwd(mv1, ta_w, ta_b)
         m_c = (mv1 * a_t.unsqueeze(1)).mean(-1)
-        a_c = 1.0 + torch.sigmoid(F.linear(F.relu(F.linear(m_c, f1w, f1b)), f2w, f2b))
-        return a_s, a_t, a_c
+        h = linear_fwd(m_c, f1w, f1b, 1)
+        a_c = linear_fwd(h, f2w, f2b, 2)
+        return a_s, a_t, a_c, m_c, h
 
     @staticmethod
     def forward(ctx, y, sa_w, sa_b, ta_w, ta_b, f1w, f1b, f2w, f2b):
@@ -381,47 +519,45 @@ class STCAttentionFunction(torch.autograd.Function):
         N, C, T, V = y.shape
         par = (sa_w, sa_b, ta_w, ta_b, f1w, f1b, f2w, f2b)
         _, m_s = stc_row_reduce(y, want_v=True, scale_v=1.0 / T)                         # mean_t y
-        a_s, _, _ = STCAttentionFunction._gates(m_s, None, *par)
-        a_s = a_s.contiguous()
+        a_s = STCAttentionFunction._gates(m_s, None, *par)[0]
         mv1, _ = stc_row_reduce(y, wv=a_s, want_t=True, scale_t=1.0 / V)                 # mean_v y*(1+se_s)
-        _, a_t, a_c = STCAttentionFunction._gates(m_s, mv1, *par, a_s=a_s)
-        a_t, a_c = a_t.contiguous(), a_c.contiguous()
+        _, a_t, a_c, m_c, h = STCAttentionFunction._gates(m_s, mv1, *par, a_s=a_s)
         out = torch.empty_like(y)
         _lib.check(_L().agcn_stc_apply(_lib.ptr(y), _lib.ptr(a_s), _lib.ptr(a_t), _lib.ptr(a_c), _lib.ptr(out), N, C, T,
                                        V, _lib.stream()), "agcn_stc_apply")
-        ctx.save_for_backward(y, m_s, mv1, a_s, a_t, a_c, *par)
+        ctx.save_for_backward(y, m_s, mv1, a_s, a_t, a_c, m_c, h, *par)
         return out
 
     @staticmethod
     def backward(ctx, dout):
-        y, m_s, mv1, a_s, a_t, a_c, *par = ctx.saved_tensors
+        y, m_s, mv1, a_s, a_t, a_c, m_c, h, *par = ctx.saved_tensors
+        sa_w, sa_b, ta_w, ta_b, f1w, f1b, f2w, f2b = par
         dout = dout.contiguous()
         N, C, T, V = y.shape
         # one pass over (dout, y): P1[n,c,t] = sum_v a_s dout*y ; P2[n,c,v] = sum_t a_t dout*y
         P1, P2 = stc_row_reduce(y, g=dout, wv=a_s, wt=a_t, want_t=True, want_v=True)
-        da_c = (P1 * a_t.unsqueeze(1)).sum(-1)
+        da_c = (P1 * a_t.unsqueeze(1)).sum(-1).contiguous()
         da_t = (P1 * a_c.unsqueeze(-1)).sum(1)
         da_s = (P2 * a_c.unsqueeze(-1)).sum(1)
-        with torch.enable_grad():
-            mv1_ = mv1.detach().requires_grad_(True)
-            p_tc = [p.detach().requires_grad_(True) for p in par[2:]]
-            _, a_t_, a_c_ = STCAttentionFunction._gates(None, mv1_, None, None, *p_tc, a_s=a_s)
-            g_tc = torch.autograd.grad([a_t_, a_c_], [mv1_] + p_tc, [da_t, da_c])
-        dmv1 = (g_tc[0] / V).contiguous()               # mv1 = (1/V) sum_v y*a_s
+        # channel gate: a_c = 1 + sigmoid(fc2(relu(fc1(m_c)))), m_c = mean_t(a_t * mv1)
+        dh, df2w, df2b = linear_bwd(da_c, a_c, h, f2w, 2)
+        dm_c, df1w, df1b = linear_bwd(dh, h, m_c, f1w, 1)
+        da_t = (da_t + (dm_c.unsqueeze(-1) * mv1).sum(1) / T).contiguous()
+        dmv1 = dm_c.unsqueeze(-1) * a_t.unsqueeze(1) / T
+        # temporal gate: a_t = 1 + sigmoid(conv_9(mv1))
+        dmv1_t, dta_w, dta_b = gate_conv_bwd(da_t, a_t, mv1, ta_w)
+        dmv1 = ((dmv1 + dmv1_t) / V).contiguous()       # mv1 = (1/V) sum_v y*a_s
         # its two other consumers: y (folded into the apply pass below) and a_s
         _, R = stc_row_reduce(y, wt=dmv1, want_v=True)
-        da_s = da_s + R.sum(1)
-        with torch.enable_grad():
-            m_s_ = m_s.detach().requires_grad_(True)
-            p_s = [p.detach().requires_grad_(True) for p in par[:2]]
-            a_s_, _, _ = STCAttentionFunction._gates(m_s_, None, *p_s, None, None, None, None, None, None)
-            g_s = torch.autograd.grad(a_s_, [m_s_] + p_s, da_s)
-        dms = (g_s[0] / T).contiguous()                 # m_s = (1/T) sum_t y
+        da_s = (da_s + R.sum(1)).contiguous()
+        # spatial gate: a_s = 1 + sigmoid(conv_V(m_s)), m_s = (1/T) sum_t y
+        dm_s, dsa_w, dsa_b = gate_conv_bwd(da_s, a_s, m_s, sa_w)
+        dms = (dm_s / T).contiguous()
         dy = torch.empty_like(y)
         _lib.check(_L().agcn_stc_bwd_apply(_lib.ptr(dout), _lib.ptr(a_s), _lib.ptr(a_t), _lib.ptr(a_c), _lib.ptr(dmv1),
                                            _lib.ptr(dms), _lib.ptr(dy), N, C, T, V, _lib.stream()),
                    "agcn_stc_bwd_apply")
-        return (dy, g_s[1], g_s[2]) + tuple(g_tc[1:])
+        return dy, dsa_w, dsa_b, dta_w, dta_b, df1w, df1b, df2w, df2b
 
 
 class BNState:

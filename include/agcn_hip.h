@@ -250,13 +250,49 @@ int agcn_bn_bwd(const float* dout, const void* mask, int mask_bits, const float*
  *   (forward: mean_t y, mean_v y*(1+se_s); backward: the two weighted sums of dout*y in one pass, and sum_t dmv*y);
  * agcn_stc_apply: out = y * a_s[n,v] * a_t[n,t] * a_c[n,c] with a_* = 1 + sigmoid gate, (N,V) / (N,T) / (N,C);
  * agcn_stc_bwd_apply: dy = dout * a_s a_t a_c + dmv[n,c,t] * a_s[n,v] + dms[n,c,v] (the gradients that reach y through
- *   the two means folded into the same pass).  The few-KB gate networks stay host tensor code. */
+ *   the two means folded into the same pass).  The gate networks themselves: agcn_gate_conv_* / agcn_linear_* below. */
 int agcn_stc_row_reduce(const float* y, const float* g, const float* wv, const float* wt, int wt_per_row, float* out_t,
                         float* out_v, float scale_t, float scale_v, int N, int C, int T, int V, void* stream);
 int agcn_stc_apply(const float* y, const float* a_s, const float* a_t, const float* a_c, float* out, int N, int C, int T,
                    int V, void* stream);
 int agcn_stc_bwd_apply(const float* dout, const float* a_s, const float* a_t, const float* a_c, const float* dmv,
                        const float* dms, float* dy, int N, int C, int T, int V, void* stream);
+
+/* ---- the small operators around the unit stack, deterministic (csrc/small_ops.hip) -----------------------------------
+ * Every sum in a fixed order, no vendor library: the model path is bitwise reproducible from process to process
+ * (MIOpen's Conv1d for the temporal gate was not: DESIGN.md section 3).
+ *
+ * data_bn  replaces agcn.py:143,163-165 (x.permute(0,4,3,1,2).view(N, M*V*C, T) -> BatchNorm1d -> view/permute ->
+ *   (N*M, C, T, V)) and aagcn.py forward_preprocess.  x is the model input (N, C, T, V, M); channel ch = (m*V+v)*C + c.
+ *   agcn_data_bn_stats: part [N][2][C*V*M] partial (sum, sumsq), finalised by agcn_bn_stats_finalize(part, N, C*V*M,
+ *   count = N*T, ...); agcn_data_bn_apply: out[(n*M+m), c, t, v] = x[n,c,t,v,m]*scale[ch] + shift[ch];
+ *   agcn_data_bn_bwd_reduce: part [N][2][C*V*M] partial (sum dy, sum dy*xhat) (agcn_colsum over N slots);
+ *   agcn_data_bn_bwd_apply: dx from the GLOBAL sums [2][C*V*M] and the element count per channel behind them. */
+int agcn_data_bn_stats(const float* x, float* part, int N, int C, int T, int V, int M, void* stream);
+int agcn_data_bn_apply(const float* x, const float* scale, const float* shift, float* out, int N, int C, int T, int V,
+                       int M, void* stream);
+int agcn_data_bn_bwd_reduce(const float* dy, const float* x, const float* mean, const float* invstd, float* part, int N,
+                            int C, int T, int V, int M, void* stream);
+int agcn_data_bn_bwd_apply(const float* dy, const float* x, const float* gamma, const float* mean, const float* invstd,
+                           const float* sums, double count, float* dx, int N, int C, int T, int V, int M, void* stream);
+/* global average pool  replaces agcn.py:179-181 (x.view(N, M, C, -1).mean(3).mean(1)): x (N*M, C, P) -> pooled (N, C);
+ * rowmean: scratch of N*M*C floats.  agcn_pool_bwd: dx[(n*M+m), c, p] = dpooled[n, c] / (M*P). */
+int agcn_pool_fwd(const float* x, float* rowmean, float* pooled, int N, int M, int C, int P, void* stream);
+int agcn_pool_bwd(const float* dpooled, float* dx, int N, int M, int C, int P, void* stream);
+/* small Linear  replaces agcn.py:183 (self.fc) and aagcn.py:111-116 (fc1c -> ReLU -> fc2c -> sigmoid):
+ * out[n, o] = act(b[o] + sum_k in[n, k] w[o, k]); act 0 identity, 1 ReLU, 2 "1 + sigmoid" (the gate's y*s + y factor).
+ * agcn_linear_bwd: dpre (N, O) scratch = dout * act'(out); din (N, K, may be NULL), dw (O, K), db (O, may be NULL). */
+int agcn_linear_fwd(const float* in, const float* w, const float* b, float* out, int N, int K, int O, int act,
+                    void* stream);
+int agcn_linear_bwd(const float* dout, const float* out, const float* in, const float* w, float* dpre, float* din,
+                    float* dw, float* db, int N, int K, int O, int act, void* stream);
+/* gate convolution  replaces aagcn.py:72-76 / 92-96 (Conv1d(C -> 1, Ks, padding (Ks-1)/2) + sigmoid on (N, C, L)):
+ * a[n, l] = 1 + sigmoid(b + sum_c sum_k w[c, k] in[n, c, l + k - pad]); Ks odd.
+ * agcn_gate_conv_bwd: da = gradient w.r.t. a; dpre (N, L) scratch; din (N, C, L), dw (C, Ks), db (1). */
+int agcn_gate_conv_fwd(const float* in, const float* w, const float* b, float* a, int N, int C, int L, int Ks,
+                       void* stream);
+int agcn_gate_conv_bwd(const float* da, const float* a, const float* in, const float* w, float* dpre, float* din,
+                       float* dw, float* db, int N, int C, int L, int Ks, void* stream);
 
 /* ---- training-step tail on one flat parameter buffer ----------------------------------------------------------------
  * replaces processor.py:698 (clip_grad_norm_(params, 1.0)) + :703 (optimizer.step() of optim.SGD(momentum, nesterov,

@@ -634,3 +634,103 @@ def test_absmax_pass_is_exact():
             out = torch.zeros(1, device=dev)
             lib.check(L.agcn_absmax(x.data_ptr(), n, out.data_ptr(), lib.stream()), 'absmax')
             assert float(out) == float(x.abs().max()), (n, off)
+
+
+@pytest.mark.parametrize('case', [(4, 3, 20, 25, 2), (3, 3, 17, 18, 2), (2, 3, 9, 25, 1)])
+def test_data_bn_prologue_fwd_bwd(case):
+    """Model prologue (reference agcn.py:163-165): permute/view -> BatchNorm1d(M*V*C) over (N, T) -> view/permute, as the
+    deterministic HIP kernels (ops.DataBNFunction) vs the same tensor code in fp64: output, dx, dweight, dbias and the
+    running statistics, train and eval."""
+    from agcn_amd import ops
+    dev = _gpu()
+    N, C, T, V, M = case
+    g = torch.Generator().manual_seed(5 + T)
+    x = (rnd(g, N, C, T, V, M) * 2 + 0.5).requires_grad_(True)
+    w = (0.5 + torch.rand(M * V * C, generator=g, dtype=torch.float64)).requires_grad_(True)
+    b = rnd(g, M * V * C, scale=0.3).requires_grad_(True)
+    rm0, rv0 = rnd(g, M * V * C, scale=0.2), 0.5 + torch.rand(M * V * C, generator=g, dtype=torch.float64)
+    r = rnd(g, N * M, C, T, V)
+
+    def ref(training):
+        rm, rv = rm0.clone(), rv0.clone()
+        h = x.permute(0, 4, 3, 1, 2).contiguous().view(N, M * V * C, T)
+        h = F.batch_norm(h, rm, rv, w, b, training, 0.1, 1e-5)
+        return h.view(N, M, V, C, T).permute(0, 1, 3, 4, 2).contiguous().view(N * M, C, T, V), rm, rv
+    for training in (True, False):
+        for t in (x, w, b):
+            t.grad = None
+        yr, rmr, rvr = ref(training)
+        xg = x.detach().float().to(dev).requires_grad_(True)
+        wg = w.detach().float().to(dev).requires_grad_(True)
+        bg = b.detach().float().to(dev).requires_grad_(True)
+        rm, rv = rm0.float().to(dev), rv0.float().to(dev)
+        y = ops.DataBNFunction.apply(xg, wg, bg, rm, rv, training, None)
+        assert rel(y, yr) < TOL
+        assert rel(rm, rmr) < TOL and rel(rv, rvr) < TOL
+        if training:
+            (yr * r).sum().backward()
+            (y * r.float().to(dev)).sum().backward()
+            assert rel(xg.grad, x.grad) < TOL
+            assert rel(wg.grad, w.grad) < TOL and rel(bg.grad, b.grad) < TOL
+
+
+@pytest.mark.parametrize('case', [(3, 2, 64, 7, 25, 60), (2, 2, 256, 5, 18, 400), (4, 1, 32, 3, 25, 7)])
+def test_pool_fc_head_fwd_bwd(case):
+    """Model epilogue (agcn.py:179-183): x.view(N, M, C, -1).mean(3).mean(1) -> Linear, ops.PoolFCFunction vs fp64."""
+    from agcn_amd import ops
+    dev = _gpu()
+    N, M, C, T, V, K = case
+    g = torch.Generator().manual_seed(77 + C)
+    x = rnd(g, N * M, C, T, V).requires_grad_(True)
+    w = rnd(g, K, C, scale=0.1).requires_grad_(True)
+    b = rnd(g, K, scale=0.1).requires_grad_(True)
+    r = rnd(g, N, K)
+    ref = F.linear(x.view(N, M, C, -1).mean(3).mean(1), w, b)
+    (ref * r).sum().backward()
+    xg, wg, bg = [t.detach().float().to(dev).requires_grad_(True) for t in (x, w, b)]
+    out = ops.PoolFCFunction.apply(xg, wg, bg, M)
+    (out * r.float().to(dev)).sum().backward()
+    assert rel(out, ref) < TOL
+    for a, b_ in ((xg, x), (wg, w), (bg, b)):
+        den = max(1e-30, float(b_.grad.abs().max()))
+        assert float((a.grad.double().cpu() - b_.grad).abs().max()) / den < 2e-4
+
+
+@pytest.mark.parametrize('case', [(3, 64, 25, 25), (2, 128, 40, 9), (2, 256, 75, 9), (2, 32, 18, 17), (5, 16, 300, 9)])
+def test_gate_conv_and_linear_kernels(case):
+    """agcn_gate_conv_* (Conv1d(C -> 1, Ks, 'same') + 1 + sigmoid, aagcn.py:72-76 / 92-96) and agcn_linear_* (act 0/1/2)
+    vs fp64 tensor code, forward and every gradient; and twice in a row bit for bit."""
+    from agcn_amd import ops
+    dev = _gpu()
+    N, C, L, Ks = case
+    g = torch.Generator().manual_seed(31 + C + L)
+    x = rnd(g, N, C, L).requires_grad_(True)
+    w = rnd(g, 1, C, Ks, scale=0.5 / np.sqrt(C)).requires_grad_(True)
+    b = rnd(g, 1, scale=0.1).requires_grad_(True)
+    da = rnd(g, N, L)
+    ref = 1 + torch.sigmoid(F.conv1d(x, w, b, padding=(Ks - 1) // 2)).squeeze(1)
+    (ref * da).sum().backward()
+    xg, wg, bg = [t.detach().float().to(dev) for t in (x, w, b)]
+    a = ops.gate_conv_fwd(xg, wg, bg)
+    assert rel(a, ref) < TOL
+    dx, dw, db = ops.gate_conv_bwd(da.float().to(dev), a, xg, wg)
+    dx2, dw2, db2 = ops.gate_conv_bwd(da.float().to(dev), a, xg, wg)
+    assert torch.equal(dx, dx2) and torch.equal(dw, dw2) and torch.equal(db, db2)
+    for got, want in ((dx, x.grad), (dw, w.grad), (db, b.grad)):
+        den = max(1e-30, float(want.abs().max()))
+        assert float((got.double().cpu() - want).abs().max()) / den < 2e-4
+    for act in (0, 1, 2):
+        xi = rnd(g, N, C).requires_grad_(True)
+        wl = rnd(g, C // 2, C, scale=1 / np.sqrt(C)).requires_grad_(True)
+        bl = rnd(g, C // 2, scale=0.1).requires_grad_(True)
+        pre = F.linear(xi, wl, bl)
+        ref = pre if act == 0 else (F.relu(pre) if act == 1 else 1 + torch.sigmoid(pre))
+        do = rnd(g, N, C // 2)
+        (ref * do).sum().backward()
+        xi_g, wl_g, bl_g = [t.detach().float().to(dev) for t in (xi, wl, bl)]
+        out = ops.linear_fwd(xi_g, wl_g, bl_g, act)
+        assert rel(out, ref) < TOL
+        din, dwl, dbl = ops.linear_bwd(do.float().to(dev), out, xi_g, wl_g, act)
+        for got, want in ((din, xi.grad), (dwl, wl.grad), (dbl, bl.grad)):
+            den = max(1e-30, float(want.abs().max()))
+            assert float((got.double().cpu() - want).abs().max()) / den < 2e-4

@@ -129,14 +129,42 @@ def run(name, dev, out):
 FIXTURES = ['m_ntu_b1', 'am_ntu_l3_t32', 'am_ntu_b1_t64']
 
 
+def csrc_fingerprint():
+    """sha256 over the kernel sources and the host operator chain: the build a set of pinned digests is valid for."""
+    import glob
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    h = hashlib.sha256()
+    files = sorted(glob.glob(os.path.join(root, '2s-agcn_amd', 'csrc', '*.hip')) +
+                   glob.glob(os.path.join(root, '2s-agcn_amd', 'csrc', '*.h')) +
+                   [os.path.join(root, '2s-agcn_amd', 'ops.py'), os.path.join(root, '2s-agcn_amd', 'model', 'agcn.py'),
+                    os.path.join(root, '2s-agcn_amd', 'model', 'aagcn.py')])
+    for f in files:
+        h.update(os.path.basename(f).encode())
+        with open(f, 'rb') as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
 def main():
     import agcn_amd  # noqa: F401
     dev = torch.device('cuda:0')
-    names = [a for a in sys.argv[1:] if a in FIXTURES] or FIXTURES
-    lines = []
+    args = sys.argv[1:]
+    write = None
+    if '--write' in args:
+        write = args[args.index('--write') + 1]
+    names = [a for a in args if a in FIXTURES] or FIXTURES
+    lines, digests = [], {}
     for name in names:
-        run(name, dev, lines)
+        digests[name] = run(name, dev, lines)
     print('\n'.join(lines))
+    if write:
+        import json
+        with open(write, 'w') as f:
+            json.dump({'_meta': {'csrc_sha': csrc_fingerprint(), 'device': torch.cuda.get_device_name(0),
+                                 'torch': torch.__version__,
+                                 'what': 'sha256(logits bytes + flat parameter-gradient bytes) of one seeded training '
+                                         'forward+backward per fixture (tools/stage_checksums.py)'},
+                       'digests': digests}, f, indent=1)
 
 
 if __name__ == '__main__':
