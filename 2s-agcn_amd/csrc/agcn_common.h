@@ -77,6 +77,7 @@ int agcn_bf16_conv1_bwd_data(const float* dy, const float* w, float* dx, int acc
 bool agcn_gcn_chain_supported(int M, int K, int V);
 int agcn_chain_f16x3();                       // 1: the chain runs on f16x3 (split_f16.h), 0: bf16x6 / AGCN_GEMM's mode
 int agcn_gcn_chain_tiles(int T);
+int agcn_gcn_chain_stats_slots(int N, int M, int K, int T, int V);
 size_t agcn_gcn_chain_workspace(int M, int K, int K2, int T, int V);
 int agcn_gcn_chain(int mode, const float* in, const float* adj, const float* wcat, const float* bias, float* out,
                    float* stats_part, int accumulate, const float* add1, const float* mask1, const float* add2,

@@ -626,6 +626,13 @@ int agcn_gcn_stats_tiles(int C, int Cout, int T, int V) {
   return agcn_conv_num_tiles(V, T);
 }
 
+// total slots (all samples) of the same partials: what the caller allocates (the persistent chain kernel writes one slot
+// per (sample, frame split), whose count depends on N)
+int agcn_gcn_stats_slots(int N, int C, int Cout, int T, int V) {
+  if (agcn_chained() && C >= 32 && agcn_gcn_chain_supported(Cout, C, V)) return agcn_gcn_chain_stats_slots(N, Cout, C, T, V);
+  return N * agcn_conv_num_tiles(V, T);
+}
+
 // y[n][o][t,v] = bias[o] + sum_{c,k} w[o][c][k] x[n][c][(t*stride + k - pad), v]      (unit_tcn conv, 1x1 convs)
 int agcn_conv_fwd_ex(const float* x, const float* w, const float* bias, float* y, float* stats_part, void* workspace,
                      size_t workspace_bytes, int N, int Cin, int Cout, int T, int V, int taps, int stride,

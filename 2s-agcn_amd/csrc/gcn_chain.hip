@@ -512,6 +512,587 @@ __global__ void __launch_bounds__(NW * 64, 2) gcn_chain_kernel(const ChainArgs a
   }
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// Weight-stationary, persistent variant of the chain (f16x3 only) for K <= 64 streamed channels (round 3).
+//
+// The tile-per-workgroup kernel above spends 90 % of a 64-row workgroup's life outside the matrix pipe: every 4-frame tile
+// pays the adjacency conversion, the staging of its 6 weight images through registers, 6 barriers, and an epilogue nothing
+// overlaps.  Here ONE workgroup per CU (8 waves = 8 frames per tile) keeps
+//   * all weight images of its 64-row block (3*K*64 two-plane fp16 = 48 KB at K = 64, + 8 KB per plain stage) and
+//   * the sample's three adjacencies (fp16 planes, 12 KB)
+// in LDS for its whole life and walks the frames [f0, f1) of its sample.  Per tile and wave (one frame):
+//   * the x fragments (lane = channel, 8 consecutive joints) come STRAIGHT from global memory / L2 into registers, 16-byte
+//     buffer loads issued one tile ahead (range-checked: rows past the sample read as 0) -- no x tile in LDS, no barrier on
+//     the input side;
+//   * 6 (+ plain) stages of  aggregate (6 MFMAs) -> split G in registers -> project (6*TM MFMAs), straight-line;
+//   * the accumulators go through ONE LDS tile O [rows][8 frames * V] (two barriers per tile); its rows are stored (bias,
+//     residual / accumulate operands, ReLU, BatchNorm partials) as whole 16-byte granules WHILE the next tile's matrix work
+//     runs: the row-store of tile k is cut into pieces that are interleaved with the stages of tile k+1.
+// BatchNorm partials stay in registers across tiles (a thread always owns the same granules of the tile) and are combined
+// once per workgroup in a fixed order: one stats slot per (sample, frame split).
+// ------------------------------------------------------------------------------------------------------------------
+constexpr int WS_NW = 8;                  // matrix waves = frames per tile
+constexpr int WS_SW = 4;                  // store waves
+constexpr int WS_NT = (WS_NW + WS_SW) * 64, WS_ST = WS_SW * 64;
+
+struct WsGeom {
+  int nmb, nsplit, fper, OPf, ngran;      // row blocks, frame splits per sample, frames per split, O pitch (floats), granules
+  unsigned gpr_magic;                     // ceil(2^32 / (OPf / 4)): granule index -> row by one multiply-high
+  int off_adj, off_o;                     // LDS byte offsets (weights at 0)
+  int o_tiles;                            // 2: O double-buffered (the store waves read tile k-1 while tile k is written)
+  size_t smem_bytes, img_bytes;
+};
+
+template <int TM>
+static inline WsGeom ws_geometry(int N, int M, int K, int K2, int T, int V) {
+  constexpr int BM = TM * 32;
+  WsGeom g;
+  g.nmb = (M + BM - 1) / BM;
+  const int ntile = (T + WS_NW - 1) / WS_NW;
+  long want = (256 + (long)N * g.nmb - 1) / ((long)N * g.nmb);       // workgroups ~ one per CU
+  if (const char* e = getenv("AGCN_WS_SPLIT")) want = atoi(e);     // test knob: frame splits per sample (read per call)
+  if (want < 1) want = 1;
+  if (want > ntile) want = ntile;
+  const int tps = (int)((ntile + want - 1) / want);                   // tiles per split
+  g.fper = tps * WS_NW;
+  g.nsplit = (ntile + tps - 1) / tps;
+  g.OPf = (WS_NW * V + 3) & ~3;
+  g.ngran = BM * (g.OPf / 4);
+  g.gpr_magic = (unsigned)((0x100000000ull + (unsigned)(g.OPf / 4) - 1) / (unsigned)(g.OPf / 4));
+  const int stages = 3 * ((K + CB - 1) / CB) + (K2 + CB - 1) / CB;
+  const size_t a_img = (size_t)2 * 2 * TM * 1024;
+  g.img_bytes = (size_t)stages * a_img;
+  g.off_adj = (int)g.img_bytes;
+  g.off_o = g.off_adj + 3 * 2 * 2 * 2 * 32 * 16;
+  const size_t o_bytes = (size_t)BM * g.OPf * 4;
+  g.o_tiles = (K2 == 0 && (size_t)g.off_o + 2 * o_bytes <= 160 * 1024) ? 2 : 1;   // double-buffered O: one barrier per tile
+  g.smem_bytes = (size_t)g.off_o + g.o_tiles * o_bytes;
+  return g;
+}
+
+// Roles: waves 0..7 = matrix waves (one frame each), waves 8..11 = store waves (the O tile of the PREVIOUS tile -> HBM while
+// the matrix waves work on the current one).  Two barriers per tile, executed by both roles:
+//     matrix: [stages of tile k] C [accumulators -> O] E            store: [rows of tile k-1] C  E
+// C = every store wave is done reading O, E = O of tile k is complete.
+// ROLES = (NCB2 == 0), the forward: separate store waves (12 waves, 168 registers each).  With plain stages (the backward-
+// data call with its fused 1x1 term: HBM-bound, it moves 1.35 GB at the 64-channel layers against 33 GFLOP) the eight
+// matrix waves keep 256 registers and store the previous tile's rows themselves, one piece of granules after every stage.
+// EXTRAS: the row-store takes accumulate / residual / mask operands or a ReLU (backward-data, inference); the training
+// forward's store is bias + BatchNorm partials only and compiles to a fraction of the code (the general store, unrolled
+// over a thread's granules, is tens of KB of instructions: it thrashed the instruction cache of the plain forward).
+template <int TM, int KCB, int NCB2, bool EXTRAS>
+__global__ void __launch_bounds__(NCB2 == 0 ? WS_NT : WS_NW * 64, NCB2 == 0 ? 3 : 2)
+gcn_ws_kernel(const ChainArgs a, const WsGeom g) {
+  constexpr bool ROLES = (NCB2 == 0);
+  constexpr int NTHREADS = ROLES ? WS_NT : WS_NW * 64;      // threads of the workgroup
+  constexpr int STT = ROLES ? WS_ST : WS_NW * 64;           // threads that store rows
+  constexpr int BM = TM * 32;
+  constexpr int A_IMG = 2 * 2 * TM * 1024;            // bytes of one stage's two-plane weight image
+  constexpr int S1 = 3 * KCB, S = S1 + NCB2;
+  constexpr bool STATS = (NCB2 == 0);                 // BatchNorm partials: the training forward only (registers)
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  unsigned char* wimg = smem;
+  unsigned char* adjq = smem + g.off_adj;             // [i][plane][ks][h][v][8 u] fp16
+  float* O0 = reinterpret_cast<float*>(smem + g.off_o);
+  const int o_stride = (g.o_tiles == 2) ? BM * g.OPf : 0;     // floats between the two O tiles (0: single buffer)
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int lr = lane & 31, h = lane >> 5;
+  const int V = a.V, T = a.T;
+  const long P = (long)T * V;
+  const int bid = blockIdx.x;
+  const unsigned long long tk_entry = (a.dbg & 8) ? wall_clock64() : 0;     // AGCN_WS_DBG & 8: see the end of the kernel
+  const int split = bid % g.nsplit;
+  const int mbk = (bid / g.nsplit) % g.nmb;
+  const int n = bid / (g.nsplit * g.nmb);
+  const int m0 = mbk * BM;
+  const int f0 = split * g.fper, f1 = min(T, f0 + g.fper);
+  const int OPf = g.OPf, GPR = OPf >> 2;
+
+  // (the matrix waves' first fragments are issued before everything else: see below)
+  // ---- resident state: weight images of this row block, the sample's adjacencies ----
+  {
+    const u32x4* src = reinterpret_cast<const u32x4*>(a.wp) + (long)mbk * S * (A_IMG / 16);
+    u32x4* dst = reinterpret_cast<u32x4*>(wimg);
+    for (int e = tid; e < S * (A_IMG / 16); e += NTHREADS) dst[e] = src[e];
+    const float* adjn = a.adj + (long)n * 3 * V * V;
+    for (int e = tid; e < 3 * 2 * 2 * 32 * 4; e += NTHREADS) {         // one pair (u, u+1) per iteration
+      const int e2 = e & 3, col = (e >> 2) & 31, hh = (e >> 7) & 1, ks = (e >> 8) & 1, i = e >> 9;
+      float v[2];
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        const int u = 16 * ks + 8 * hh + 2 * e2 + q;
+        const bool ok = u < V && col < V;
+        const int gi = ok ? (a.adj_t ? ((i * V + col) * V + u) : ((i * V + u) * V + col)) : 0;
+        const float tv = adjn[gi];
+        v[q] = ok ? tv : 0.f;
+      }
+      unsigned p0, p1;
+      split_pair_f16(v[0], v[1], p0, p1);
+      const int o = (((ks * 2 + hh) * 32) + col) * 16 + e2 * 4;
+      *reinterpret_cast<unsigned*>(adjq + (i * 2 + 0) * 2048 + o) = p0;
+      *reinterpret_cast<unsigned*>(adjq + (i * 2 + 1) * 2048 + o) = p1;
+    }
+  }
+  const int ntiles = (f1 - f0 + WS_NW - 1) / WS_NW;
+
+  float rs_s = 1.f, rs_inv = 1.f;                     // f16x3 range scale of the streamed operands and its inverse
+  {
+    float mx = a.in_absmax ? *a.in_absmax : 0.f;
+    if (a.in2_absmax) mx = fmaxf(mx, *a.in2_absmax);
+    f16_range_scale_of<8>(mx, rs_s, rs_inv);
+  }
+  // ---- row-store machinery (store waves when ROLES, else the matrix waves themselves) ----
+  // A store wave owns whole rows of the O tile: row r = sw + NSW * u, lane <-> 16-byte granule (floats 4 lane .. 4 lane + 3)
+  // of the row, so one wave-instruction moves one contiguous run of a row (800 bytes at V = 25), the row offset is a scalar
+  // (soffset of the buffer instruction), the bias and every bounds test but "lane < granules per row" are wave-uniform, and
+  // the BatchNorm partials of a row live in one register pair per (lane, row) that is summed across lanes once at the end.
+  constexpr int NSW = ROLES ? WS_SW : WS_NW;          // waves that store rows
+  constexpr int RPW = BM / NSW;                       // rows per store wave
+  constexpr int RBW = ROLES ? 4 : 2;                  // rows per batch (their loads are all issued before the first use;
+  constexpr int RB = RPW < RBW ? RPW : RBW;           //  the matrix waves of !ROLES have few registers to spare)
+  const int sw = ROLES ? wave - WS_NW : wave;         // (negative in the matrix waves of ROLES: unused there)
+  float st_s[STATS ? RPW : 1], st_q[STATS ? RPW : 1];
+#pragma unroll
+  for (int u = 0; u < (STATS ? RPW : 1); ++u) { st_s[u] = 0.f; st_q[u] = 0.f; }
+  const bool al16 = ((P & 3) == 0);                   // rows of the output are 16-byte aligned (f0 is a multiple of 8)
+  // every operand of the row-store is addressed through a range-checked buffer descriptor over THIS row block of the
+  // sample (rows m0 .. m0 + BM - 1, clipped to M: loads past it give 0, stores are dropped)
+  const int rows_ok = min(BM, a.M - m0);
+  const long blk0 = ((long)n * a.M + m0) * P;         // first element of the row block in the (N, M, T, V) tensors
+  const int blk_bytes = (int)((long)rows_ok * P * 4);
+  auto mk = [&](const void* p, int bytes) __attribute__((always_inline)) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, p ? bytes : 0, 0x00020000);
+  };
+  const __amdgpu_buffer_rsrc_t r_out = mk(a.out + blk0, blk_bytes);
+  const __amdgpu_buffer_rsrc_t r_a1 = mk(a.add1 ? a.add1 + blk0 : nullptr, blk_bytes);
+  const __amdgpu_buffer_rsrc_t r_a2 = mk(a.add2 ? a.add2 + blk0 : nullptr, blk_bytes);
+  // masks: fp32 tensors like the operands, or sign-bit words (bit e of word w <-> element 32 w + e)
+  const int sh0 = (int)(blk0 & 31);
+  const int mbytes = a.mask_bits ? (int)((((long)rows_ok * P + sh0 + 31) >> 5) * 4) : blk_bytes;
+  const __amdgpu_buffer_rsrc_t r_m1 =
+      mk(a.mask1 ? (a.mask_bits ? (const void*)(reinterpret_cast<const unsigned*>(a.mask1) + (blk0 >> 5)) : (const void*)(a.mask1 + blk0)) : nullptr, mbytes);
+  const __amdgpu_buffer_rsrc_t r_m2 =
+      mk(a.mask2 ? (a.mask_bits ? (const void*)(reinterpret_cast<const unsigned*>(a.mask2) + (blk0 >> 5)) : (const void*)(a.mask2 + blk0)) : nullptr, mbytes);
+  // element offset eo (inside the row block) -> 16 bytes / one float / ReLU-mask bits
+  auto ld4 = [&](const __amdgpu_buffer_rsrc_t& r, int voff, int soff) __attribute__((always_inline)) {
+    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0));
+  };
+  auto ld1 = [&](const __amdgpu_buffer_rsrc_t& r, int eo) __attribute__((always_inline)) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, eo * 4, 0, 0));
+  };
+  auto mask4 = [&](const __amdgpu_buffer_rsrc_t& r, int eo) __attribute__((always_inline)) {   // eo a multiple of 4
+    if (a.mask_bits) {
+      const int b = sh0 + eo;
+      return (__builtin_amdgcn_raw_buffer_load_b32(r, (b >> 5) * 4, 0, 0) >> (b & 31)) & 15u;
+    }
+    const f32x4 m = ld4(r, eo * 4, 0);
+    return (m[0] > 0.f ? 1u : 0u) | (m[1] > 0.f ? 2u : 0u) | (m[2] > 0.f ? 4u : 0u) | (m[3] > 0.f ? 8u : 0u);
+  };
+  auto mask1b = [&](const __amdgpu_buffer_rsrc_t& r, int eo) __attribute__((always_inline)) {
+    if (a.mask_bits) {
+      const int b = sh0 + eo;
+      return ((__builtin_amdgcn_raw_buffer_load_b32(r, (b >> 5) * 4, 0, 0) >> (b & 31)) & 1u) != 0u;
+    }
+    return ld1(r, eo) > 0.f;
+  };
+  struct Extras { f32x4 o, acc, a1, a2; unsigned m1, m2; };
+  const int q = lane * 4;                             // first float of this lane's granule
+  float bias_r[RPW];                                  // bias of this wave's rows (uniform values, loaded once)
+#pragma unroll
+  for (int u = 0; u < RPW; ++u) {
+    const int r = sw + NSW * u;
+    bias_r[u] = (a.bias && r >= 0 && r < rows_ok) ? a.bias[m0 + r] : 0.f;
+  }
+  // rows [b0, b0 + RB) of this wave, frames t0s .. of the tile, `nvalid` valid floats per row (a multiple of 4 here)
+  auto store_rows_fast = [&](const float* O, int b0, int t0s, int nvalid) __attribute__((always_inline)) {
+    Extras ex[RB];
+    const bool on = q < nvalid;                        // (lanes beyond the row idle)
+#pragma unroll
+    for (int u = 0; u < RB; ++u) {
+      const int r = sw + NSW * (b0 + u);               // wave-uniform
+      if (r >= rows_ok || !on) continue;
+      ex[u].o = *reinterpret_cast<const f32x4*>(O + r * OPf + q);
+      if constexpr (EXTRAS) {
+        const int ro = (r * T + t0s) * V;              // scalar: first element of the row's run
+        ex[u].m1 = ex[u].m2 = 15u;
+        if (a.accumulate) ex[u].acc = ld4(r_out, q * 4, ro * 4);
+        if (a.add1) { ex[u].a1 = ld4(r_a1, q * 4, ro * 4); if (a.mask1) ex[u].m1 = mask4(r_m1, ro + q); }
+        if (a.add2) { ex[u].a2 = ld4(r_a2, q * 4, ro * 4); if (a.mask2) ex[u].m2 = mask4(r_m2, ro + q); }
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < RB; ++u) {
+      const int r = sw + NSW * (b0 + u);
+      if (r >= rows_ok || !on || (a.dbg & 4)) continue;
+      const float bval = bias_r[b0 + u];
+      f32x4 v = ex[u].o;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] = v[e] * rs_inv + bval;      // (the accumulators carry the range scale)
+      if constexpr (STATS) {
+        if (a.stats) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) { st_s[b0 + u] += v[e]; st_q[b0 + u] += v[e] * v[e]; }
+        }
+      }
+      if constexpr (EXTRAS) {
+        if (a.accumulate) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] += ex[u].acc[e];
+        }
+        if (a.add1) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] += ((ex[u].m1 >> e) & 1u) ? ex[u].a1[e] : 0.f;
+        }
+        if (a.add2) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] += ((ex[u].m2 >> e) & 1u) ? ex[u].a2[e] : 0.f;
+        }
+        if (a.relu) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+        }
+      }
+      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), r_out, q * 4, (r * T + t0s) * V * 4, 0);
+    }
+  };
+  // rows that are not 16-byte aligned (T*V not a multiple of 4) or a partial tile whose run is not a multiple of 4 floats:
+  // element by element, deliberately compact code (rare: odd shapes and at most the last tile of a frame range)
+  auto store_rows_slow = [&](const float* O, int b0, int t0s, int nvalid) __attribute__((always_inline)) {
+#pragma unroll
+    for (int u = 0; u < RB; ++u) {
+      const int r = sw + NSW * (b0 + u);
+      if (r >= rows_ok || (a.dbg & 4)) continue;
+      const float bval = bias_r[b0 + u];
+      const int ro = (r * T + t0s) * V;
+      float ss = 0.f, sq = 0.f;
+#pragma unroll 1
+      for (int e = 0; e < 4; ++e) {
+        if (q + e >= nvalid) break;
+        const float z = O[r * OPf + q + e] * rs_inv + bval;
+        ss += z;
+        sq += z * z;
+        float y = z;
+        if constexpr (EXTRAS) {
+          const int eo = ro + q + e;
+          if (a.accumulate) y += ld1(r_out, eo);
+          if (a.add1) y += (!a.mask1 || mask1b(r_m1, eo)) ? ld1(r_a1, eo) : 0.f;
+          if (a.add2) y += (!a.mask2 || mask1b(r_m2, eo)) ? ld1(r_a2, eo) : 0.f;
+          if (a.relu) y = fmaxf(y, 0.f);
+        }
+        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, y), r_out, (ro + q + e) * 4, 0, 0);
+      }
+      if constexpr (STATS) {
+        if (a.stats) { st_s[b0 + u] += ss; st_q[b0 + u] += sq; }
+      }
+    }
+  };
+  auto store_tile = [&](const float* O, int t0s, int nvalid) __attribute__((always_inline)) {
+    const bool fast = al16 && (nvalid & 3) == 0;       // wave-uniform
+#pragma unroll
+    for (int b0 = 0; b0 < RPW; b0 += RB) {
+      if (fast) store_rows_fast(O, b0, t0s, nvalid);
+      else store_rows_slow(O, b0, t0s, nvalid);
+    }
+  };
+  // BatchNorm partials of this wave's rows: lanes summed in a fixed butterfly order, one slot per (sample, frame split)
+  auto store_stats = [&]() __attribute__((always_inline)) {
+    if constexpr (STATS) {
+      if (!a.stats) return;
+      const long slot = (long)n * g.nsplit + split;
+#pragma unroll
+      for (int u = 0; u < RPW; ++u) {
+        float s1 = st_s[u], s2 = st_q[u];
+#pragma unroll
+        for (int k = 32; k >= 1; k >>= 1) { s1 += __shfl_xor(s1, k); s2 += __shfl_xor(s2, k); }
+        const int r = sw + NSW * u;
+        if (lane == 0 && r < rows_ok) {
+          a.stats[(slot * 2 + 0) * a.M + m0 + r] = s1;
+          a.stats[(slot * 2 + 1) * a.M + m0 + r] = s2;
+        }
+      }
+    }
+  };
+
+  if (ROLES && wave >= WS_NW) {
+    // =================================== store role ===================================
+    __builtin_amdgcn_s_setprio(3);                      // few, latency-bound instructions: ahead of the matrix waves' stream
+    __syncthreads();                                    // (resident images in place: the matrix waves start)
+    const unsigned long long tk_pro = (a.dbg & 8) ? wall_clock64() : 0;
+    unsigned long long tk_loop = 0;
+    for (int k = 0; k <= ntiles; ++k) {                 // (one call site of the store code: instruction-cache footprint)
+      if (k == ntiles && (a.dbg & 8)) tk_loop = wall_clock64();
+      if (k > 0) {
+        const int t0s = f0 + (k - 1) * WS_NW;
+        store_tile(O0 + ((k - 1) & 1) * o_stride, t0s, min(WS_NW, f1 - t0s) * V);
+      }
+      if (k == ntiles) break;
+      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // C: done reading O (tile k-1)
+      if (o_stride == 0) asm volatile("s_barrier" ::: "memory");        // E: O of tile k is complete (single buffer)
+    }
+    store_stats();
+    if ((a.dbg & 8) && tid == WS_NW * 64) {             // (debug run: overwrites 4 outputs of this workgroup's block)
+      float* o = a.out + blk0 + (long)f0 * V + 16;
+      o[0] = (float)(tk_pro - tk_entry); o[1] = (float)(tk_loop - tk_pro); o[2] = (float)(wall_clock64() - tk_loop);
+      o[3] = -54321.f;
+    }
+    return;
+  }
+
+  // =================================== matrix role ===================================
+  // ---- streamed operands: range-checked buffer loads (a row past the sample reads as 0) ----
+  const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(a.in + (long)n * a.K * P), 0, (int)((long)a.K * P * 4), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rx2 = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(NCB2 ? a.in2 + (long)n * a.K2 * P : a.in), 0, NCB2 ? (int)((long)a.K2 * P * 4) : 0, 0x00020000);
+  // x fragment of channel block cb, k-step ks: joints 16 ks + 8 h + [0, 8) of channel 32 cb + lr, frame t
+  int xoff[KCB];
+#pragma unroll
+  for (int cb = 0; cb < KCB; ++cb) xoff[cb] = (int)(((long)min(cb * CB + lr, a.K - 1) * P + 8 * h) * 4);
+  auto load_x = [&](int t, int cb, f32x4 (&xc)[4]) __attribute__((always_inline)) {
+    const int tb = t * V * 4;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {                       // q = 2 ks + half: floats 16 ks + 4 (q & 1)
+      const u32x4 r = __builtin_amdgcn_raw_buffer_load_b128(rx, xoff[cb] + tb + ((q >> 1) * 16 + (q & 1) * 4) * 4, 0, 0);
+      xc[q] = __builtin_bit_cast(f32x4, r);
+    }
+  };
+  // plain-stage operand of 32-channel block s2 at frame t (16 scalar loads: lanes = joints, coalesced 100-byte runs)
+  auto load_p = [&](int s2, int t, float (&dv)[16]) __attribute__((always_inline)) {
+    const int pos = (t * V + min(lr, V - 1)) * 4;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+      const int c2 = min(s2 * CB + (j & 3) + 8 * (j >> 2) + 4 * h, a.K2 - 1);
+      dv[j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rx2, (int)((long)c2 * P * 4) + pos, 0, 0));
+    }
+  };
+  // one 16-deep step of the three fp16 products (smallest first)
+  auto mfma3 = [&](const bf16x8 (&x)[2], const bf16x8 (&y)[2], f32x16 c) __attribute__((always_inline)) {
+    c = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, x[1]), __builtin_bit_cast(f16x8, y[0]), c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, x[0]), __builtin_bit_cast(f16x8, y[1]), c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, x[0]), __builtin_bit_cast(f16x8, y[0]), c, 0, 0, 0);
+    return c;
+  };
+  auto split8 = [&](const float (&v)[8], bf16x8 (&q)[2], float sc) __attribute__((always_inline)) {
+    u32x4 w0, w1;
+#pragma unroll
+    for (int e2 = 0; e2 < 4; ++e2) {
+      unsigned p0, p1;
+      split_pair_f16_mix(v[2 * e2] * sc, v[2 * e2 + 1] * sc, p0, p1);
+      w0[e2] = p0; w1[e2] = p1;
+    }
+    q[0] = __builtin_bit_cast(bf16x8, w0);
+    q[1] = __builtin_bit_cast(bf16x8, w1);
+  };
+  auto splitx = [&](const f32x4 (&xc)[4], bf16x8 (&xq)[2][2]) __attribute__((always_inline)) {
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      float xv[8];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { xv[e] = xc[2 * ks][e]; xv[4 + e] = xc[2 * ks + 1][e]; }
+      split8(xv, xq[ks], rs_s);
+    }
+  };
+  // G = X[cb] . A^_i for this wave's frame (6 MFMAs)
+  auto aggregate = [&](const bf16x8 (&xq)[2][2], int i) __attribute__((always_inline)) {
+    f32x16 d;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) d[j] = 0.f;
+    const unsigned char* aq = adjq + i * 2 * 2048 + (h * 32 + lr) * 16;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      bf16x8 bq[2];
+#pragma unroll
+      for (int pl = 0; pl < 2; ++pl) bq[pl] = *reinterpret_cast<const bf16x8*>(aq + pl * 2048 + ks * 1024);
+      d = mfma3(xq[ks], bq, d);
+    }
+    return d;
+  };
+  // the 16 values of a lane (one 32-channel block, this lane's joint) -> the two k-steps of the projection's B operand
+  auto gsplit = [&](const float (&dv)[16], bf16x8 (&gb)[2][2], float sc) __attribute__((always_inline)) {
+#pragma unroll
+    for (int hf = 0; hf < 2; ++hf) {
+      float gv[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) gv[e] = dv[8 * hf + e];
+      split8(gv, gb[hf], sc);
+    }
+  };
+  auto project = [&](int stage, const bf16x8 (&gb)[2][2], f32x16 (&acc)[TM]) __attribute__((always_inline)) {
+    const unsigned char* ab = wimg + stage * A_IMG + lane * 16;
+#pragma unroll
+    for (int hf = 0; hf < 2; ++hf)
+#pragma unroll
+      for (int tm = 0; tm < TM; ++tm) {
+        bf16x8 af[2];
+#pragma unroll
+        for (int pl = 0; pl < 2; ++pl) af[pl] = *reinterpret_cast<const bf16x8*>(ab + ((pl * 2 + hf) * TM + tm) * 1024);
+        acc[tm] = mfma3(af, gb[hf], acc[tm]);
+      }
+  };
+
+  // ONE fragment register set: channel block 0 of a tile is loaded at the middle of the previous tile (and consumed at the
+  // tile's first instruction), blocks 1.. of a tile right after that (consumed two and a half stages later).
+  f32x4 xr[4];
+  float dvb[16];
+  const int t_first = f0 + wave;
+  if (t_first < f1) load_x(t_first, 0, xr);
+  __syncthreads();                                      // resident images in place
+  const unsigned long long tk_pro = (a.dbg & 8) ? wall_clock64() : 0;
+  const unsigned long long ck_pro = (a.dbg & 8) ? clock64() : 0;        // shader clock: loop cycles -> in-kernel frequency
+
+  long long ck_st = 0, ck_c = 0, ck_o = 0, ck_e = 0, ck0 = 0;   // (dbg & 8) cycles in stages / barrier C / O write / barrier E
+  int prev_t0 = -1;                                     // (!ROLES) tile whose rows are still to be stored
+  for (int t0 = f0; t0 < f1; t0 += WS_NW) {
+    const int t = t0 + wave;
+    const bool fvalid = t < f1 && !(a.dbg & 1);         // wave-uniform
+    const bool nvalid_next = (t + WS_NW) < f1 && !(a.dbg & 2);
+    f32x16 acc[TM];
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+      for (int j = 0; j < 16; ++j) acc[tm][j] = 0.f;
+    if (a.dbg & 8) ck0 = clock64();
+    if (fvalid) {
+      // Software pipeline over the stages, interleaved BY HAND (hipcc puts each stage's register split behind its twelve
+      // projection MFMAs and reads every LDS fragment right in front of its use; the split's mixed-precision fmas are inline
+      // asm, which sched_group_barrier cannot place).  Stage s:
+      //     aggregate(s+1): 6 MFMAs on adjacency fragments that were read during stage s-1
+      //     2*TM projection steps of stage s: [weight fragments of the NEXT step] [3 MFMAs] [a slice of the split of G(s+1)]
+      // with a scheduling fence after every step, so the order written here is the order issued.
+      if (NCB2 > 0) load_p(0, t, dvb);                  // first plain operand: in flight during the aggregated stages
+      bf16x8 xq[2][2];
+      u32x4 gw[2][2][2];                                // [stage parity][k-step half][plane]: B operand of the projection
+      bf16x8 bq[2][2];                                  // adjacency fragments [k-step][plane] of the next aggregation
+      auto load_adj = [&](int i) __attribute__((always_inline)) {
+        const unsigned char* aq = adjq + i * 2 * 2048 + (h * 32 + lr) * 16;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+          for (int pl = 0; pl < 2; ++pl) bq[ks][pl] = *reinterpret_cast<const bf16x8*>(aq + pl * 2048 + ks * 1024);
+      };
+      auto agg = [&]() __attribute__((always_inline)) {
+        f32x16 d;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) d[j] = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) d = mfma3(xq[ks], bq[ks], d);
+        return d;
+      };
+      // pairs [p0, p0 + np) of the 8 value pairs of a lane's 16 values -> the two fp16 planes (pair p: half p >> 2, dword p & 3)
+      auto split_pairs = [&](const float (&dv)[16], int p0, int np, u32x4 (&gwn)[2][2], float sc) __attribute__((always_inline)) {
+#pragma unroll
+        for (int p = p0; p < p0 + np; ++p) {
+          unsigned w0, w1;
+          split_pair_f16_mix(dv[2 * p] * sc, dv[2 * p + 1] * sc, w0, w1);
+          gwn[p >> 2][0][p & 3] = w0;
+          gwn[p >> 2][1][p & 3] = w1;
+        }
+      };
+      auto load_w = [&](int stage, int st, bf16x8 (&af)[2]) __attribute__((always_inline)) {
+        const int hf = st / TM, tm = st - hf * TM;
+        const unsigned char* ab = wimg + stage * A_IMG + lane * 16;
+#pragma unroll
+        for (int pl = 0; pl < 2; ++pl) af[pl] = *reinterpret_cast<const bf16x8*>(ab + ((pl * 2 + hf) * TM + tm) * 1024);
+      };
+      constexpr int NST = 2 * TM;                       // projection steps per stage
+      // value pairs of G(s+1) split behind step st: none behind step 0 (the aggregation that produces them was issued just
+      // before it: its six MFMAs have to drain first), the eight pairs spread over the remaining steps
+      constexpr int PP0[4] = {0, 0, 3, 6}, PPN[4] = {0, 3, 3, 2};       // NST == 4
+      constexpr int QP0[2] = {0, 0}, QPN[2] = {0, 8};                   // NST == 2
+      splitx(xr, xq);
+      if (KCB > 1) load_x(t, 1, xr);                    // (the registers just consumed take the next channel block)
+      else if (nvalid_next) load_x(t + WS_NW, 0, xr);
+      load_adj(0);
+      {
+        const f32x16 d = agg();
+        load_adj(S1 > 1 ? 1 : 0);
+        float dv[16];
+#pragma unroll
+        for (int j = 0; j < 16; ++j) dv[j] = d[j];
+        split_pairs(dv, 0, 8, gw[0], 1.f);
+      }
+      bf16x8 afc[2], afn[2];
+      load_w(0, 0, afc);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int s = 0; s < S; ++s) {
+        const int sn = s + 1;
+        float dv[16];
+        if (sn < S1) {
+          if (sn % 3 == 0) {                            // next channel block: its x fragment
+            splitx(xr, xq);
+            if (sn / 3 + 1 < KCB) load_x(t, sn / 3 + 1, xr);
+            else if (nvalid_next) load_x(t + WS_NW, 0, xr);          // the next tile's first block
+          }
+          const f32x16 dn = agg();                      // (its adjacency fragments were read during the previous stage)
+#pragma unroll
+          for (int j = 0; j < 16; ++j) dv[j] = dn[j];
+        } else if (sn < S) {
+#pragma unroll
+          for (int j = 0; j < 16; ++j) dv[j] = dvb[j];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int st = 0; st < NST; ++st) {
+          if (!(a.dbg & 32)) {
+            if (st + 1 < NST) load_w(s, st + 1, afn);
+            else if (sn < S) load_w(sn, 0, afn);
+          }
+          if (st == NST - 2 && sn + 1 < S1 && !(a.dbg & 64)) load_adj((sn + 1) % 3);   // fragments of the aggregation after the next one
+          __builtin_amdgcn_sched_barrier(0);            // (the LDS reads of the next step go out BEFORE this step's MFMAs)
+          {
+            const int hf = st / TM, tm = st - hf * TM;
+            bf16x8 gbv[2] = {__builtin_bit_cast(bf16x8, gw[s & 1][hf][0]), __builtin_bit_cast(bf16x8, gw[s & 1][hf][1])};
+            acc[tm] = mfma3(afc, gbv, acc[tm]);
+          }
+          if (sn < S && !(a.dbg & 16)) split_pairs(dv, NST == 4 ? PP0[st] : QP0[st], NST == 4 ? PPN[st] : QPN[st], gw[sn & 1], sn < S1 ? 1.f : rs_s);
+          afc[0] = afn[0]; afc[1] = afn[1];
+          __builtin_amdgcn_sched_barrier(0);
+        }
+        if (sn >= S1 && sn + 1 < S) load_p(sn + 1 - S1, t, dvb);     // (the plain operand just split: its registers are free)
+        if constexpr (!ROLES) {                         // a batch of the previous tile's rows after each of the first stages
+          if (prev_t0 >= 0 && s * RB < RPW) {
+            if (al16) store_rows_fast(O0, s * RB, prev_t0, WS_NW * V); else store_rows_slow(O0, s * RB, prev_t0, WS_NW * V);
+          }
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+    }
+    if constexpr (!ROLES) {
+      if (prev_t0 >= 0 && !fvalid) store_tile(O0, prev_t0, WS_NW * V);     // (no stages ran in this wave: all its rows now)
+      prev_t0 = t0;
+    }
+    if (a.dbg & 8) { const long long c = clock64(); ck_st += c - ck0; ck0 = c; }
+    // single O tile: barrier C (everyone is done reading the previous tile's O), write, barrier E (O complete).
+    // two O tiles (ROLES): write tile k's buffer straight away, ONE barrier (the store waves have finished tile k-1's
+    // buffer when they arrive, i.e. before anyone overwrites it at tile k+1)
+    if (o_stride == 0) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    if (a.dbg & 8) { const long long c = clock64(); ck_c += c - ck0; ck0 = c; }
+    if (fvalid && lr < V) {
+      float* O = O0 + (((t0 - f0) / WS_NW) & 1) * o_stride;
+#pragma unroll
+      for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+        for (int j = 0; j < 16; ++j) O[(tm * 32 + mfma_row(j, h)) * OPf + wave * V + lr] = acc[tm][j];   // (still range-scaled)
+    }
+    if (a.dbg & 8) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); const long long c = clock64(); ck_o += c - ck0; ck0 = c; }
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");     // E: O of this tile is complete
+    if (a.dbg & 8) { const long long c = clock64(); ck_e += c - ck0; ck0 = c; }
+  }
+  const unsigned long long tk_loop = (a.dbg & 8) ? wall_clock64() : 0;
+  if ((a.dbg & 8) && tid == 0) {                        // (debug run: overwrites 4 outputs of this workgroup's block)
+    float* o = a.out + blk0 + (long)f0 * V;
+    o[0] = (float)(tk_pro - tk_entry); o[1] = (float)(tk_loop - tk_pro); o[2] = (float)(clock64() - ck_pro); o[3] = -12345.f;
+    o[4] = (float)ck_st; o[5] = (float)ck_c; o[6] = (float)ck_o; o[7] = (float)ck_e;
+  }
+  if constexpr (!ROLES) {
+    store_tile(O0, prev_t0, min(WS_NW, f1 - prev_t0) * V);  // the last tile's rows
+    store_stats();
+  }
+}
+
 struct ChainGeom {
   int ntiles, ncb, nmb, XP, off_bias;
   size_t smem_bytes, pack_bytes;
@@ -591,6 +1172,87 @@ int chain_launch(ChainArgs a, const float* w, long sa_m, long sa_i, long sa_c, c
   hipLaunchKernelGGL(kern, dim3((unsigned)(a.N * g.ntiles * g.nmb)), dim3(NW * 64), g.smem_bytes, stream, a);
   AGCN_NOTE_KERNEL("gcn_chain_kernel<%d, %d, %d, %s>", TM, VS, NW, F16 ? "true" : "false");
   return agcn_check_launch();
+}
+
+
+// ---- weight-stationary launch (see gcn_ws_kernel) ----
+static inline bool ws_enabled() {
+  static const int on = getenv("AGCN_CHAIN_WS") ? atoi(getenv("AGCN_CHAIN_WS")) : 1;
+  return on != 0;
+}
+// shapes the persistent kernel takes: f16x3 chain, 33..64 streamed channels, up to three plain 32-channel stages
+static inline bool ws_shape_ok(int M, int K, int K2, int V) {
+  return agcn_chain_f16x3() && ws_enabled() && K > 32 && K <= 64 && V <= 32 && M >= 1 && K2 >= 0 && K2 <= 96;
+}
+
+template <int TM, int NCB2>
+int ws_launch(ChainArgs a, const float* w, long sa_m, long sa_i, long sa_c, const ChainW2& g_w2, void* ws, size_t ws_bytes,
+              hipStream_t stream) {
+  constexpr int KCB = 2;
+  const WsGeom g = ws_geometry<TM>(a.N, a.M, a.K, a.K2, a.T, a.V);
+  if (g.smem_bytes > 160 * 1024) return AGCN_ERR_UNSUPPORTED;
+  if (NCB2 > 0 && a.stats) return AGCN_ERR_UNSUPPORTED;            // (BatchNorm partials: plain-stage-free forward only)
+  const size_t img_total = (size_t)g.nmb * g.img_bytes;
+  if (img_total + 16 > ws_bytes) return AGCN_ERR_WORKSPACE;
+  unsigned* amax = reinterpret_cast<unsigned*>(static_cast<char*>(ws) + img_total);
+  if (!a.in_absmax) {
+    if (int rc = agcn_launch_absmax(a.in, (long)a.N * a.K * a.T * a.V, amax, stream)) return rc;
+    a.in_absmax = reinterpret_cast<const float*>(amax);
+  }
+  if (a.in2 && !a.in2_absmax) {
+    if (int rc = agcn_launch_absmax(a.in2, (long)a.N * a.K2 * a.T * a.V, amax + 1, stream)) return rc;
+    a.in2_absmax = reinterpret_cast<const float*>(amax + 1);
+  }
+  if (!a.in2) a.in2_absmax = nullptr;
+  a.ncb = KCB; a.ncb2 = NCB2; a.nmb = g.nmb;
+  a.wp = (const unsigned short*)ws;
+  const int s_total = 3 * KCB + NCB2;
+  ChainPackArgs pk;
+  pk.w = w; pk.wp = (unsigned short*)ws; pk.M = a.M; pk.K = a.K; pk.ncb = KCB;
+  pk.sa_m = sa_m; pk.sa_i = sa_i; pk.sa_c = sa_c;
+  pk.nsub = 3; pk.s_total = s_total; pk.s_off = 0;
+  hipLaunchKernelGGL((chain_pack_kernel<TM, true>), dim3(g.nmb * KCB * 3), dim3(256), 0, stream, pk);
+  int rc = agcn_check_launch();
+  if (rc) return rc;
+  if (NCB2 > 0) {
+    ChainPackArgs p2;
+    p2.w = g_w2.w; p2.wp = (unsigned short*)ws; p2.M = a.M; p2.K = a.K2; p2.ncb = NCB2;
+    p2.sa_m = g_w2.sa_m; p2.sa_i = 0; p2.sa_c = g_w2.sa_c;
+    p2.nsub = 1; p2.s_total = s_total; p2.s_off = 3 * KCB;
+    hipLaunchKernelGGL((chain_pack_kernel<TM, true>), dim3(g.nmb * NCB2), dim3(256), 0, stream, p2);
+    rc = agcn_check_launch();
+    if (rc) return rc;
+  }
+  const bool extras = NCB2 > 0 || a.accumulate || a.add1 || a.add2 || a.relu;
+  const dim3 grid((unsigned)(a.N * g.nmb * g.nsplit)), block(NCB2 == 0 ? WS_NT : WS_NW * 64);
+  if (extras) {
+    auto kern = gcn_ws_kernel<TM, KCB, NCB2, true>;
+    static unsigned char lds_ok[AGCN_MAX_DEVICES] = {};
+    if (int e = agcn_allow_big_lds_rt(reinterpret_cast<const void*>(kern), lds_ok)) return e;
+    hipLaunchKernelGGL(kern, grid, block, g.smem_bytes, stream, a, g);
+  } else {
+    if constexpr (NCB2 == 0) {
+      auto kern = gcn_ws_kernel<TM, KCB, 0, false>;
+      static unsigned char lds_ok[AGCN_MAX_DEVICES] = {};
+      if (int e = agcn_allow_big_lds_rt(reinterpret_cast<const void*>(kern), lds_ok)) return e;
+      hipLaunchKernelGGL(kern, grid, block, g.smem_bytes, stream, a, g);
+    }
+  }
+  AGCN_NOTE_KERNEL("gcn_ws_kernel<%d, %d, %d>", TM, KCB, NCB2);
+  return agcn_check_launch();
+}
+
+template <int TM>
+int ws_dispatch(const ChainArgs& a, const float* w, long sa_m, long sa_i, long sa_c, const ChainW2& w2, void* ws,
+                size_t ws_bytes, hipStream_t stream) {
+  const int ncb2 = a.in2 ? (a.K2 + CB - 1) / CB : 0;
+  switch (ncb2) {
+    case 0: return ws_launch<TM, 0>(a, w, sa_m, sa_i, sa_c, w2, ws, ws_bytes, stream);
+    case 1: return ws_launch<TM, 1>(a, w, sa_m, sa_i, sa_c, w2, ws, ws_bytes, stream);
+    case 2: return ws_launch<TM, 2>(a, w, sa_m, sa_i, sa_c, w2, ws, ws_bytes, stream);
+    case 3: return ws_launch<TM, 3>(a, w, sa_m, sa_i, sa_c, w2, ws, ws_bytes, stream);
+  }
+  return AGCN_ERR_UNSUPPORTED;
 }
 
 template <int TM, int NW>
@@ -921,6 +1583,16 @@ bool agcn_gcn_chain_supported(int M, int K, int V) { return M >= 1 && K >= 1 && 
 
 int agcn_gcn_chain_tiles(int T) { return (T + chain_waves() - 1) / chain_waves(); }
 
+// total (sum, sumsq) slots of the forward's BatchNorm partials: N * tiles for the tile-per-workgroup kernel, one per
+// (sample, frame split) for the persistent one
+int agcn_gcn_chain_stats_slots(int N, int M, int K, int T, int V) {
+  if (ws_shape_ok(M, K, 0, V)) {
+    const WsGeom g = (M <= 32) ? ws_geometry<1>(N, M, K, 0, T, V) : ws_geometry<2>(N, M, K, 0, T, V);
+    if (g.smem_bytes <= 160 * 1024) return N * g.nsplit;
+  }
+  return N * agcn_gcn_chain_tiles(T);
+}
+
 // packed weight images; K2 = channels of the optional plain second source (0: none)
 size_t agcn_gcn_chain_workspace(int M, int K, int K2, int T, int V) {
   (void)T; (void)V;
@@ -953,6 +1625,12 @@ int agcn_gcn_chain(int mode, const float* in, const float* adj, const float* wca
   else           { a.M = C; a.K = Cout; a.adj_t = 1; sa_m = 1; sa_i = C; sa_c = 3L * C; }
   cw2.sa_c = a.M;        // W2[m][k] = w2[k*M + m]
   if (w2_rows_are_outputs) { cw2.sa_m = a.K2; cw2.sa_c = 1; }   // w2 (M, K2) row-major (forward: a folded 1x1 conv)
+  if (!a.dbg && ws_shape_ok(a.M, a.K, a.K2, V)) {
+    if (const char* e = getenv("AGCN_WS_DBG")) a.dbg = atoi(e);   // profiling switches of gcn_ws_kernel (read per call)              // persistent, weight-stationary kernel (64 streamed channels)
+    const int rc = (a.M <= 32) ? ws_dispatch<1>(a, wcat, sa_m, sa_i, sa_c, cw2, ws, ws_bytes, stream)
+                               : ws_dispatch<2>(a, wcat, sa_m, sa_i, sa_c, cw2, ws, ws_bytes, stream);
+    if (rc != AGCN_ERR_UNSUPPORTED) return rc;
+  }
   if (chain_waves() == 8 && chain_tm(a.M) != 1) {
     if (chain_tm(a.M) == 4) return chain_dispatch_vs<4, 8>(a, wcat, sa_m, sa_i, sa_c, cw2, ws, ws_bytes, stream);
     return chain_dispatch_vs<2, 8>(a, wcat, sa_m, sa_i, sa_c, cw2, ws, ws_bytes, stream);

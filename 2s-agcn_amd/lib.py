@@ -33,6 +33,7 @@ SIGNATURES = {
     "agcn_conv_workspace": (_Z, [_I, _I, _I, _I, _I, _I]),
     "agcn_gcn_workspace": (_Z, [_I, _I, _I, _I]),
     "agcn_gcn_stats_tiles": (_I, [_I, _I, _I, _I]),
+    "agcn_gcn_stats_slots": (_I, [_I, _I, _I, _I, _I]),
     "agcn_conv_fwd": (_I, [_P, _P, _P, _P, _P, _P, _Z, _I, _I, _I, _I, _I, _I, _I, _P]),
     "agcn_conv_bwd_data": (_I, [_P, _P, _P, _I, _P, _P, _P, _P, _P, _Z, _I, _I, _I, _I, _I, _I, _I, _P]),
     "agcn_conv_bwd_weight_workspace": (_Z, [_I, _I, _I, _I, _I, _I, _I]),

@@ -244,8 +244,7 @@ def aggregate_project_fwd(x, adj, wcat, bias, want_stats=False, x_amax=None):
     y = _empty((N, Cout, T, V), x)
     stats = None
     if want_stats:
-        nt = _L().agcn_gcn_stats_tiles(C, Cout, T, V)
-        stats = _empty((N * nt, 2, Cout), x)
+        stats = _empty((_L().agcn_gcn_stats_slots(N, C, Cout, T, V), 2, Cout), x)
     ws, nb = _gcn_ws(C, Cout, T, V, x)
     _lib.check(_L().agcn_gcn_aggregate_project_fwd_ex(_lib.ptr(x), _lib.ptr(adj), _lib.ptr(wcat), _lib.ptr(bias),
                                                       _lib.ptr(y), _lib.ptr(stats), ws.data_ptr(), nb, N, C, Cout, T, V,

@@ -78,7 +78,8 @@ int agcn_conv_bwd_weight(const float* dy, const float* x, float* dw, void* works
  * adj: (N,3,V,V) = A^ from agcn_adjacency_fwd ; wcat: (Cout, 3*C) = [Wd_0 | Wd_1 | Wd_2] ; bias: sum of the three
  * conv_d biases (or NULL). */
 size_t agcn_gcn_workspace(int C, int Cout, int T, int V);   /* aggregate fwd / bwd_data / dadj (packed weights) */
-int agcn_gcn_stats_tiles(int C, int Cout, int T, int V);    /* stats_part slots per sample written by agcn_gcn_aggregate_project_fwd */
+int agcn_gcn_stats_tiles(int C, int Cout, int T, int V);    /* stats_part slots per sample of the tile-per-workgroup kernels */
+int agcn_gcn_stats_slots(int N, int C, int Cout, int T, int V);   /* TOTAL stats_part slots agcn_gcn_aggregate_project_fwd writes (what the caller allocates: the persistent kernel's count depends on N) */
 int agcn_gcn_aggregate_project_fwd(const float* x, const float* adj, const float* wcat, const float* bias, float* y,
                                    float* stats_part, void* workspace, size_t workspace_bytes, int N, int C, int Cout,
                                    int T, int V, void* stream);

@@ -734,3 +734,66 @@ def test_gate_conv_and_linear_kernels(case):
         for got, want in ((din, xi.grad), (dwl, wl.grad), (dbl, bl.grad)):
             den = max(1e-30, float(want.abs().max()))
             assert float((got.double().cpu() - want).abs().max()) / den < 2e-4
+
+
+@pytest.mark.parametrize('case', [(2, 64, 64, 44, 25, 1), (2, 64, 64, 44, 25, 2), (3, 64, 128, 24, 25, 1),
+                                  (2, 64, 64, 20, 18, 1), (2, 64, 64, 37, 25, 1), (2, 3, 64, 40, 25, 1)])
+def test_ws_chain_multi_tile(case, monkeypatch):
+    """The persistent weight-stationary chain kernel (gcn_ws_kernel: 64 streamed channels) with SEVERAL 8-frame tiles per
+    workgroup (AGCN_WS_SPLIT pins the frame splits per sample; small test batches would otherwise get one tile per
+    workgroup): forward + BatchNorm partials, backward-data with every fused epilogue operand and the fused 1x1 term, on
+    16-byte-aligned rows (T*V % 4 == 0) and unaligned ones, a partial last tile, V = 18, and a 3-row block (first layer's
+    backward).  Against fp64 tensor code."""
+    from agcn_amd import ops
+    dev = _gpu()
+    N, C, Cout, T, V, nsplit = case
+    monkeypatch.setenv('AGCN_WS_SPLIT', str(nsplit))
+    g = torch.Generator().manual_seed(100 + C + T + V)
+    x = rnd(g, N, C, T, V).requires_grad_(True)
+    adj = rnd(g, N, 3, V, V, scale=0.3)
+    wcat = rnd(g, Cout, 3 * C, scale=1.0 / np.sqrt(3 * C))
+    bias = rnd(g, Cout, scale=0.1)
+    y_ref = _gcn_ref(x, adj, wcat, bias)
+    dy = rnd(g, *y_ref.shape)
+    y_ref.backward(dy)
+    xg, ag, wg, bg, dyg = [t.detach().float().to(dev) for t in (x, adj, wcat, bias, dy)]
+    L = ops._L()
+    ws_mode = L.agcn_chain_mode().decode() == 'f16x3'      # (AGCN_GEMM=f32 / bf16 runs take the generic kernels)
+    if C >= 32:
+        y, stats = ops.aggregate_project_fwd(xg, ag, wg, bg, want_stats=True)
+        assert (not ws_mode) or 'gcn_ws_kernel' in L.agcn_last_kernel().decode(), L.agcn_last_kernel()
+        assert rel(y, y_ref) < TOL
+        s = stats.double().sum(0).cpu()
+        assert rel(s[0], y_ref.detach().sum((0, 2, 3))) < TOL * 10
+        assert rel(s[1], (y_ref.detach() ** 2).sum((0, 2, 3))) < TOL * 10
+        y2, _ = ops.aggregate_project_fwd(xg, ag, wg, bg, want_stats=False)
+        assert torch.equal(y, y2)
+    if Cout != 64:
+        return
+    # backward-data: streamed source = dy (64 channels)
+    a1, m1, a2, m2 = [rnd(g, N, C, T, V).float().to(dev) for _ in range(4)]
+    prior = rnd(g, N, C, T, V).float().to(dev)
+
+    def pack(m):
+        b = np.packbits((m.flatten() > 0).cpu().numpy(), bitorder='little')
+        b = np.concatenate([b, np.zeros((-len(b)) % 4, np.uint8)])
+        return torch.from_numpy(b.view(np.int32).copy()).to(dev)
+    dx = ops.aggregate_project_bwd_data(dyg, ag, wg, tuple(x.shape))
+    assert (not ws_mode) or 'gcn_ws_kernel' in L.agcn_last_kernel().decode(), L.agcn_last_kernel()
+    assert rel(dx, x.grad) < TOL
+    ref2 = x.grad.float().to(dev) + prior + a1 * (m1 > 0) + a2 * (m2 > 0)
+    dx2 = ops.aggregate_project_bwd_data(dyg, ag, wg, tuple(x.shape), out=prior.clone(), accumulate=True, add1=a1,
+                                         mask1=m1, add2=a2, mask2=m2)
+    assert rel(dx2, ref2) < TOL
+    dx4 = ops.aggregate_project_bwd_data(dyg, ag, wg, tuple(x.shape), out=prior.clone(), accumulate=True, add1=a1,
+                                         mask1=pack(m1), add2=a2, mask2=pack(m2))
+    assert torch.equal(dx4, dx2)
+    if C >= 32 and ops.fused_bwd_data_supported(C, Cout, V):
+        K2 = 6 * (Cout // 4)
+        dtp = rnd(g, N, K2, T, V)
+        wab = rnd(g, K2, C, scale=1.0 / np.sqrt(K2))
+        ref5 = x.grad + torch.einsum('kc,nktv->nctv', wab, dtp) + (a1 * (m1 > 0)).double().cpu()
+        dx5 = ops.aggregate_project_bwd_data(dyg, ag, wg, tuple(x.shape), add1=a1, mask1=pack(m1),
+                                             dtp=dtp.float().to(dev), wab=wab.float().to(dev).view(K2, C, 1, 1))
+        assert (not ws_mode) or 'gcn_ws_kernel<2, 2, 3>' in L.agcn_last_kernel().decode(), L.agcn_last_kernel()
+        assert rel(dx5, ref5) < TOL
