@@ -559,7 +559,8 @@ static inline WsGeom ws_geometry(int N, int M, int K, int K2, int T, int V) {
   g.OPf = (WS_NW * V + 3) & ~3;
   g.ngran = BM * (g.OPf / 4);
   g.gpr_magic = (unsigned)((0x100000000ull + (unsigned)(g.OPf / 4) - 1) / (unsigned)(g.OPf / 4));
-  const int stages = 3 * ((K + CB - 1) / CB) + (K2 + CB - 1) / CB;
+  const int kcb = (K <= 64) ? 2 : 4;                               // channel blocks of the kernel instantiation (ws_dispatch)
+  const int stages = 3 * kcb + (K2 + CB - 1) / CB;
   const size_t a_img = (size_t)2 * 2 * TM * 1024;
   g.img_bytes = (size_t)stages * a_img;
   g.off_adj = (int)g.img_bytes;
@@ -1180,15 +1181,17 @@ static inline bool ws_enabled() {
   static const int on = getenv("AGCN_CHAIN_WS") ? atoi(getenv("AGCN_CHAIN_WS")) : 1;
   return on != 0;
 }
-// shapes the persistent kernel takes: f16x3 chain, 33..64 streamed channels, up to three plain 32-channel stages
+// shapes the persistent kernel takes: f16x3 chain, 33..64 streamed channels with up to three plain 32-channel stages, or
+// 65..128 streamed channels without plain stages (96 KB of resident weights per 64-row block, single O tile)
 static inline bool ws_shape_ok(int M, int K, int K2, int V) {
-  return agcn_chain_f16x3() && ws_enabled() && K > 32 && K <= 64 && V <= 32 && M >= 1 && K2 >= 0 && K2 <= 96;
+  if (!(agcn_chain_f16x3() && ws_enabled() && V <= 32 && M >= 1 && K > 32)) return false;
+  static const int k128 = getenv("AGCN_WS_K128") ? atoi(getenv("AGCN_WS_K128")) : 1;
+  return (K <= 64 && K2 >= 0 && K2 <= 96) || (k128 && K <= 128 && K2 == 0 && M > 32);
 }
 
-template <int TM, int NCB2>
+template <int TM, int NCB2, int KCB = 2>
 int ws_launch(ChainArgs a, const float* w, long sa_m, long sa_i, long sa_c, const ChainW2& g_w2, void* ws, size_t ws_bytes,
               hipStream_t stream) {
-  constexpr int KCB = 2;
   const WsGeom g = ws_geometry<TM>(a.N, a.M, a.K, a.K2, a.T, a.V);
   if (g.smem_bytes > 160 * 1024) return AGCN_ERR_UNSUPPORTED;
   if (NCB2 > 0 && a.stats) return AGCN_ERR_UNSUPPORTED;            // (BatchNorm partials: plain-stage-free forward only)
@@ -1246,6 +1249,12 @@ template <int TM>
 int ws_dispatch(const ChainArgs& a, const float* w, long sa_m, long sa_i, long sa_c, const ChainW2& w2, void* ws,
                 size_t ws_bytes, hipStream_t stream) {
   const int ncb2 = a.in2 ? (a.K2 + CB - 1) / CB : 0;
+  if (a.K > 64) {
+    if constexpr (TM == 2) {
+      if (ncb2 == 0) return ws_launch<2, 0, 4>(a, w, sa_m, sa_i, sa_c, w2, ws, ws_bytes, stream);
+    }
+    return AGCN_ERR_UNSUPPORTED;
+  }
   switch (ncb2) {
     case 0: return ws_launch<TM, 0>(a, w, sa_m, sa_i, sa_c, w2, ws, ws_bytes, stream);
     case 1: return ws_launch<TM, 1>(a, w, sa_m, sa_i, sa_c, w2, ws, ws_bytes, stream);

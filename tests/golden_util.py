@@ -78,6 +78,9 @@ def sens_floor(gold):
     return float(np.median(vals)) if vals else 0.0
 
 
+BAND_CAP = 5e-2
+
+
 def grad_check(g, gold, name, tol):
     """Noise-aware gradient parity.  err32 = distance to the reference run in fp32 (the parity target);
     the fixtures also hold the SAME reference code run in fp64, which gives the reference's own fp32 rounding
@@ -104,7 +107,12 @@ def grad_check(g, gold, name, tol):
         # least the model-wide median band (a flip in layer L moves the gradients of every layer below it)
         noise = max(noise, float(gold['sens.' + name]), sens_floor(gold))
     err64 = float(np.abs(a - r64).max() / scale)
-    return (err32 <= tol) or (err64 <= tol + factor * noise), err32, err64, noise
+    # the band is CAPPED: whatever the perturbation draws say, a tensor further than BAND_CAP of max|g| from the fp64
+    # reference fails (round 2's audit showed bands of 0.1-0.2 on single tensors, i.e. a criterion that could not fail;
+    # the largest deviation any correct run has shown on these fixtures is 2.2e-2).  The kink-free gradient evidence is
+    # the pinned-ReLU end-to-end tests, which assert the primary criterion.
+    band = min(factor * noise, BAND_CAP)
+    return (err32 <= tol) or (err64 <= tol + band), err32, err64, noise
 
 # ---- parity audit: every golden gradient comparison leaves a record; tests/conftest.py prints one summary line per
 # fixture at the end of the run (so the test log shows HOW each tensor passed, not just that it did) ----

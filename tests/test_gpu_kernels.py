@@ -737,7 +737,9 @@ def test_gate_conv_and_linear_kernels(case):
 
 
 @pytest.mark.parametrize('case', [(2, 64, 64, 44, 25, 1), (2, 64, 64, 44, 25, 2), (3, 64, 128, 24, 25, 1),
-                                  (2, 64, 64, 20, 18, 1), (2, 64, 64, 37, 25, 1), (2, 3, 64, 40, 25, 1)])
+                                  (2, 64, 64, 20, 18, 1), (2, 64, 64, 37, 25, 1), (2, 3, 64, 40, 25, 1),
+                                  (2, 128, 128, 28, 25, 1), (2, 128, 256, 21, 25, 2), (2, 128, 128, 22, 18, 1),
+                                  (2, 96, 64, 16, 25, 1)])
 def test_ws_chain_multi_tile(case, monkeypatch):
     """The persistent weight-stationary chain kernel (gcn_ws_kernel: 64 streamed channels) with SEVERAL 8-frame tiles per
     workgroup (AGCN_WS_SPLIT pins the frame splits per sample; small test batches would otherwise get one tile per

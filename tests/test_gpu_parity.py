@@ -167,18 +167,21 @@ def test_model_layerwise_vs_oracle_full_size():
     gu.audit_value('layerwise_m_ntu_b1(masks imposed)', f'worst param grad [{wk}]', worst[wk], GTOL)
 
 
-def test_model_end_to_end_grads_with_pinned_relu_patterns():
-    """END-TO-END gradient parity without the ReLU-kink lottery: the full NTU model (T=300) runs forward+backward on
+@pytest.mark.parametrize('fixture', ['m_ntu_b1', 'm_kin_b2'])
+def test_model_end_to_end_grads_with_pinned_relu_patterns(fixture):
+    """END-TO-END gradient parity without the ReLU-kink lottery: the full model (T=300; NTU batch 1 and Kinetics V=18,
+    400 classes, batch 2) runs forward+backward on
     the HIP path; the fp64 CPU oracle then runs the whole network end to end with every one of the 20 ReLU activation
     patterns the HIP forward produced imposed (``masks``), and ALL parameter gradients are compared at 2e-4 of the
     per-tensor max|g| -- the primary criterion, no band.  Unlike the layer-wise check, errors here accumulate through
     the whole backward pass."""
     dev = _gpu()
     from model.agcn import Model
-    gold = gu.load('m_ntu_b1')
+    gold = gu.load(fixture)
     n, v, num_class, seed, t = [int(i) for i in gold['meta']]
     sd0 = orc.randomized_state(orc.model_param_shapes(num_class, v), seed, stress=float(gold['meta.stress']))
-    model = Model(num_class=num_class, num_point=v, num_person=2, graph='graph.ntu_rgb_d.Graph',
+    model = Model(num_class=num_class, num_point=v, num_person=2,
+                  graph='graph.ntu_rgb_d.Graph' if v == 25 else 'graph.kinetics.Graph',
                   graph_args=dict(labeling_mode='spatial'))
     model.load_state_dict(sd0)
     model.to(dev).train()
@@ -198,7 +201,7 @@ def test_model_end_to_end_grads_with_pinned_relu_patterns():
     sd = orc.with_grad({kk: (vv.double() if vv.is_floating_point() else vv) for kk, vv in sd0.items()})
     lo = orc.model_forward(torch.from_numpy(xn).double(), sd, gu.graph_A(v).double(), training=True, masks=masks)
     torch.nn.functional.cross_entropy(lo, torch.from_numpy(lab)).backward()
-    fx = 'end_to_end_m_ntu_b1(all 20 ReLU patterns pinned, vs fp64 oracle)'
+    fx = f'end_to_end_{fixture}(all 20 ReLU patterns pinned, vs fp64 oracle)'
     assert gu.audit_value(fx, 'logits', gu.rel_err(logits.detach().cpu().numpy(), lo.detach().numpy()), TOL)
     errs, worst, wname = [], 0.0, ''
     for k, p in model.named_parameters():
@@ -289,6 +292,66 @@ def test_training_trace_three_steps():
         idx = gold['final.' + k + '.idx']
         ref = gold['final.' + k + '.samples'].astype(np.float64)
         assert np.abs(t.reshape(-1)[idx] - ref).max() < 2e-3 * max(1e-12, np.abs(ref).max()), k
+
+
+def test_training_trace_three_steps_with_pinned_masks():
+    """The 2e-3 of test_training_trace_three_steps is the price of ReLU kinks, not of the arithmetic: here the SAME three
+    optimisation steps run on the HIP path and, in fp64 on the CPU, through the oracle with torch.optim.SGD +
+    clip_grad_norm_ (the reference's loop, processor.py:697-703) with the HIP run's ReLU patterns of every step imposed.
+    Losses, gradient norms and the sampled parameters of all three steps then agree at the north-star 1e-4."""
+    dev = _gpu()
+    from agcn_amd.trainer import TrainEngine
+    from model.agcn import Model
+    gold = gu.load('train_trace_ntu_b2')
+    n, v, num_class, seed = [int(i) for i in gold['meta']]
+    sd0 = orc.randomized_state(orc.model_param_shapes(num_class, v), seed, stress=3.0)
+    model = Model(num_class=num_class, num_point=v, num_person=2, graph='graph.ntu_rgb_d.Graph',
+                  graph_args=dict(labeling_mode='spatial'))
+    model.load_state_dict(sd0)
+    model.to(dev)
+    eng = TrainEngine(model, base_lr=0.1, momentum=0.9, nesterov=True, weight_decay=1e-4, max_grad_norm=1.0)
+    cap = {}
+    for k in range(1, 11):
+        getattr(model, f'l{k}').register_forward_pre_hook(lambda mod, inp, k=k: cap.__setitem__(('x', k), inp[0].detach()))
+        getattr(model, f'l{k}').register_forward_hook(lambda mod, inp, out, k=k: cap.__setitem__(('y', k), out.detach()))
+    # fp64 oracle state + the reference's optimiser
+    sd = orc.with_grad({kk: (vv.double() if vv.is_floating_point() else vv) for kk, vv in sd0.items()})
+    params = [vv for kk, vv in sd.items() if not orc.is_buffer(kk)]
+    opt = torch.optim.SGD(params, lr=0.1, momentum=0.9, nesterov=True, weight_decay=1e-4)
+    A64 = gu.graph_A(v).double()
+    fx = 'train_trace_3_steps(masks of every step pinned, vs fp64 oracle)'
+    for step in range(3):
+        xn, lab = gu.model_inputs(n, v, num_class, seed + step, 300)
+        # ReLU patterns of THIS step's forward.  The GCN-core pattern needs the pre-update weights, so it is taken by the
+        # engine's before_step hook (after the backward, before clip + SGD); the extra gcn1 forwards run in train mode,
+        # their effect on the BatchNorm running statistics is undone.
+        masks = {}
+
+        def take_masks():
+            keep = {kk: vv.clone() for kk, vv in model.state_dict().items() if 'running_' in kk or 'num_batches' in kk}
+            with torch.no_grad():
+                for k in range(1, 11):
+                    g_k = getattr(model, f'l{k}').gcn1(cap[('x', k)])
+                    masks[k] = ((g_k > 0).double().cpu(), (cap[('y', k)] > 0).double().cpu())
+            model.load_state_dict(keep, strict=False)
+        loss = eng.train_step(torch.from_numpy(xn).to(dev), torch.from_numpy(lab).to(dev), before_step=take_masks)
+        lo = orc.model_forward(torch.from_numpy(xn).double(), sd, A64, training=True, masks=masks)
+        lref = torch.nn.functional.cross_entropy(lo, torch.from_numpy(lab))
+        opt.zero_grad()
+        lref.backward()
+        gn = float(torch.nn.utils.clip_grad_norm_(params, 1.0))
+        opt.step()
+        e_loss = abs(float(loss.detach()) - float(lref)) / max(1.0, abs(float(lref)))
+        e_gn = abs(eng.grad_norm() - gn) / max(1e-12, gn)
+        assert gu.audit_value(fx, f'step{step + 1}.loss', e_loss, TOL), (step, float(loss), float(lref))
+        assert gu.audit_value(fx, f'step{step + 1}.grad_norm', e_gn, 2e-4), (step, eng.grad_norm(), gn)
+    worst, wname = 0.0, ''
+    for k, p in model.named_parameters():
+        ref = sd[k].detach()
+        e = float((p.detach().double().cpu() - ref).abs().max()) / max(1e-12, float(ref.abs().max()))
+        if e > worst:
+            worst, wname = e, k
+    assert gu.audit_value(fx, f'worst parameter after 3 steps [{wname}]', worst, TOL), (worst, wname)
 
 
 def test_processor_smoke(tmp_path):
