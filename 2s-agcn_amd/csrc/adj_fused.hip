@@ -34,6 +34,8 @@ struct AfArgs {
   int N, C, Ci, T, V, tt, ntiles, nchunks, nsb;
   int npl;                     // 3: six split products (bf16x6) ; 1: hi*hi only (bf16)
   int dbg;                     // profiling aid (AGCN_AF_DBG): 1 = skip phase 2, 2 = skip the phase-1 loop
+  unsigned* x_absmax;          // fwd, optional: receives max |x| (bit pattern of a non-negative float; zeroed by the launcher):
+                               // a by-product of the one pass that reads all of x, for the f16x3 chain that reads x next
 };
 
 struct AfPackArgs {
@@ -114,6 +116,8 @@ __global__ void __launch_bounds__(NT, (TM * 16 + PD * 8 + 60 <= 128) ? 4 : 2) ad
   const bool okp = rpos < nvalid;
   const float* xrow = a.x + (long)n * a.C * P + (okp ? (g0 + rpos) : 0);
 
+  unsigned xmax = 0;                            // running max |x| of the elements this thread stages (forward, row block 0)
+  const bool track_amax = MODE == 0 && a.x_absmax != nullptr && sblk == 0;
   auto issue_loads = [&](int ch, u32x4 (&qa)[EA], float (&qb)[8]) __attribute__((always_inline)) {
     const u32x4* src = wp4 + (long)ch * A16;
 #pragma unroll
@@ -128,6 +132,10 @@ __global__ void __launch_bounds__(NT, (TM * 16 + PD * 8 + 60 <= 128) ? 4 : 2) ad
 #pragma unroll
     for (int u = 0; u < EA; ++u) reinterpret_cast<u32x4*>(Ab)[min(tid + u * NT, A16 - 1)] = qa[u];   // tail lanes rewrite unit A16-1 with its own value
     const int kc0 = ch * CK + hb * 8;
+    if (track_amax) {
+#pragma unroll
+      for (int c = 0; c < 8; ++c) xmax = max(xmax, __float_as_uint(qb[c]) & 0x7fffffffu);   // (clamped lanes repeat real elements)
+    }
     u32x4 ph, pm, pl;
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
@@ -175,6 +183,11 @@ __global__ void __launch_bounds__(NT, (TM * 16 + PD * 8 + 60 <= 128) ? 4 : 2) ad
     }
   }
 
+  if (track_amax) {                             // one atomicMax per wave (max is order-independent: deterministic)
+#pragma unroll
+    for (int k = 32; k >= 1; k >>= 1) xmax = max(xmax, (unsigned)__shfl_xor((int)xmax, k));
+    if (lane == 0) atomicMax(a.x_absmax, xmax);
+  }
   // bias of the rows this lane holds
   if (a.bias) {
 #pragma unroll
@@ -436,14 +449,26 @@ size_t agcn_adjacency_fused_workspace(int C, int Ci) {
   return af_geometry(C, 1, 25, tm * 32, nsub).pack_bytes + 256;
 }
 
+int agcn_adjacency_fused_fwd_ex(const float* x, const float* wab, const float* bab, const float* A, const float* PA,
+                                const float* alpha, float* tp_out, float* spart, float* P, float* adj, float* x_absmax_out,
+                                void* workspace, size_t workspace_bytes, int N, int C, int Ci, int T, int V, void* stream);
 int agcn_adjacency_fused_fwd(const float* x, const float* wab, const float* bab, const float* A, const float* PA,
                              const float* alpha, float* tp_out, float* spart, float* P, float* adj, void* workspace,
                              size_t workspace_bytes, int N, int C, int Ci, int T, int V, void* stream) {
+  return agcn_adjacency_fused_fwd_ex(x, wab, bab, A, PA, alpha, tp_out, spart, P, adj, nullptr, workspace, workspace_bytes,
+                                     N, C, Ci, T, V, stream);
+}
+// x_absmax_out (optional, 4 bytes): receives max |x|, a by-product of the pass (for the f16x3 chain that reads x next)
+int agcn_adjacency_fused_fwd_ex(const float* x, const float* wab, const float* bab, const float* A, const float* PA,
+                                const float* alpha, float* tp_out, float* spart, float* P, float* adj, float* x_absmax_out,
+                                void* workspace, size_t workspace_bytes, int N, int C, int Ci, int T, int V, void* stream) {
   if (!x || !wab || !PA || !spart || !P || !adj || !workspace || N <= 0 || C <= 0 || Ci <= 0 || T <= 0 || V <= 0 ||
       V > 32)
     return AGCN_ERR_ARG;
   if (!af_supported(C, Ci, T, V)) return AGCN_ERR_UNSUPPORTED;
+  if (x_absmax_out && hipMemsetAsync(x_absmax_out, 0, 4, (hipStream_t)stream) != hipSuccess) return AGCN_ERR_ARG;
   AfArgs a = {};
+  a.x_absmax = reinterpret_cast<unsigned*>(x_absmax_out);
   a.x = x; a.bias = bab; a.spart = spart; a.tp_out = tp_out;
   a.N = N; a.C = C; a.Ci = Ci; a.T = T; a.V = V;
   int rc = af_run(0, a, wab, workspace, workspace_bytes, (hipStream_t)stream);

@@ -196,9 +196,10 @@ def adjacency_recompute():
     return os.environ.get('AGCN_ADJ_RECOMPUTE', '0') == '1'
 
 
-def adjacency_fused_fwd(x, wab, bab, A, PA, alpha=None, keep_tp=False):
+def adjacency_fused_fwd(x, wab, bab, A, PA, alpha=None, keep_tp=False, x_amax_out=None):
     """P, adj straight from x: [theta;phi] = wab.x + bab is formed and reduced on chip (no tp round trip); wab
-    (6Ci, C[,1,1]).  keep_tp: also return theta/phi, written once as a by-product (never re-read by the forward)."""
+    (6Ci, C[,1,1]).  keep_tp: also return theta/phi, written once as a by-product (never re-read by the forward).
+    x_amax_out: optional 1-element tensor that receives max |x| (the pass reads all of x anyway)."""
     N, C, T, V = x.shape
     Ci = wab.shape[0] // 6
     tp = _empty((N, 6 * Ci, T, V), x) if keep_tp else None
@@ -208,10 +209,10 @@ def adjacency_fused_fwd(x, wab, bab, A, PA, alpha=None, keep_tp=False):
     adj = _empty((N, 3, V, V), x)
     nb = _L().agcn_adjacency_fused_workspace(C, Ci)
     ws = _ws(nb, x)
-    _lib.check(_L().agcn_adjacency_fused_fwd(_lib.ptr(x), _lib.ptr(wab.reshape(6 * Ci, C)), _lib.ptr(bab), _lib.ptr(A),
-                                             _lib.ptr(PA), _lib.ptr(alpha), _lib.ptr(tp), _lib.ptr(spart), _lib.ptr(P),
-                                             _lib.ptr(adj), ws.data_ptr(), nb, N, C, Ci, T, V, _lib.stream()),
-               "agcn_adjacency_fused_fwd")
+    _lib.check(_L().agcn_adjacency_fused_fwd_ex(_lib.ptr(x), _lib.ptr(wab.reshape(6 * Ci, C)), _lib.ptr(bab), _lib.ptr(A),
+                                                _lib.ptr(PA), _lib.ptr(alpha), _lib.ptr(tp), _lib.ptr(spart), _lib.ptr(P),
+                                                _lib.ptr(adj), _lib.ptr(x_amax_out), ws.data_ptr(), nb, N, C, Ci, T, V,
+                                                _lib.stream()), "agcn_adjacency_fused_fwd")
     return (P, adj, tp) if keep_tp else (P, adj)
 
 
@@ -778,27 +779,34 @@ def gcn_forward(c, x, A, PA, wab, bab, wd, bd, bn, down, training, alpha=None, a
     AGCN: adj = P + A + PA.  AAGCN: A = None, adj = PA + alpha*P.  adaptive=False (NonAdaptiveGCN): adj = A."""
     N, C, T, V = x.shape
     count = N * T * V
+    first = down is not None and first_layer_enabled() and bool(_L().agcn_gcn_first_supported(C, wd.shape[0], V))
+    # max |x| left behind by the pass that produced x (None: nobody did); the 3-channel first layer does not use it
+    x_amax = None if first else _take_out_amax(x)
     if adaptive and adjacency_fused_supported(C, wab.shape[0] // 6, T, V):
         # theta/phi are formed and reduced on chip.  A training forward either keeps nothing (the backward recomputes
         # them, adjacency_bwd with tp = None) or lets the kernel drop a copy for the backward to re-read.
         keep = training and need_bwd and not adjacency_recompute()
+        amax_here = None
+        if x_amax is None and not first and fused_amax_enabled():
+            amax_here = _empty((1,), x)    # this pass reads all of x: it takes the maximum along the way
         if keep:
-            P, adj, tp = adjacency_fused_fwd(x, wab, bab, A, PA, alpha, keep_tp=True)
+            P, adj, tp = adjacency_fused_fwd(x, wab, bab, A, PA, alpha, keep_tp=True, x_amax_out=amax_here)
         else:
             tp = None
-            P, adj = adjacency_fused_fwd(x, wab, bab, A, PA, alpha)
+            P, adj = adjacency_fused_fwd(x, wab, bab, A, PA, alpha, x_amax_out=amax_here)
+        if amax_here is not None:
+            x_amax = amax_here
     elif adaptive:
         tp, _ = conv_fwd(x, wab, bab)
         P, adj = adjacency_fwd(tp, A, PA, alpha)
     else:
         tp = P = None
         adj = A.unsqueeze(0).expand(N, 3, V, V).contiguous()
-    first = down is not None and first_layer_enabled() and bool(_L().agcn_gcn_first_supported(C, wd.shape[0], V))
     if first:
         # 3-channel first layer: aggregate+project and the `down` convolution in one pass over x (csrc/gcn_first.hip)
         ypre, st, dpre, st2 = gcn_first_fwd(x, adj, wd, bd, down[0], down[1], want_stats=training)
     else:
-        c.g_x_amax = _take_out_amax(x)     # kept for the weight gradients of the backward
+        c.g_x_amax = x_amax                # kept for the weight gradients of the backward
         ypre, st = aggregate_project_fwd(x, adj, wd, bd, want_stats=training, x_amax=c.g_x_amax)
     bn2 = None
     if not first:

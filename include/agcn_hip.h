@@ -197,6 +197,11 @@ size_t agcn_adjacency_fused_workspace(int C, int Ci);
 int agcn_adjacency_fused_fwd(const float* x, const float* wab, const float* bab, const float* A, const float* PA,
                              const float* alpha, float* tp_out, float* spart, float* P, float* adj, void* workspace,
                              size_t workspace_bytes, int N, int C, int Ci, int T, int V, void* stream);
+/* same; x_absmax_out (optional, 4 bytes) receives max |x| as a by-product of the pass that reads all of x, for the f16x3
+ * aggregate+project chain that reads x next (agcn_gcn_aggregate_project_fwd_ex) */
+int agcn_adjacency_fused_fwd_ex(const float* x, const float* wab, const float* bab, const float* A, const float* PA,
+                                const float* alpha, float* tp_out, float* spart, float* P, float* adj, float* x_absmax_out,
+                                void* workspace, size_t workspace_bytes, int N, int C, int Ci, int T, int V, void* stream);
 int agcn_adjacency_fused_bwd_scores(const float* x, const float* wab, const float* bab, const float* dS, float* dtp,
                                     float* dbpart, void* scratch, float* db, void* workspace, size_t workspace_bytes,
                                     int N, int C, int Ci, int T, int V, void* stream);

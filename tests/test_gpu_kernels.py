@@ -799,3 +799,29 @@ def test_ws_chain_multi_tile(case, monkeypatch):
                                              dtp=dtp.float().to(dev), wab=wab.float().to(dev).view(K2, C, 1, 1))
         assert (not ws_mode) or 'gcn_ws_kernel<2, 2, 3>' in L.agcn_last_kernel().decode(), L.agcn_last_kernel()
         assert rel(dx5, ref5) < TOL
+
+
+@pytest.mark.parametrize('case', [(8, 64, 64, 64, 25), (8, 128, 128, 48, 25), (6, 128, 256, 32, 25), (8, 64, 128, 56, 18)])
+def test_ws_chain_repeats_bit_for_bit(case, monkeypatch):
+    """The persistent chain kernel synchronises its matrix and store waves with one or two workgroup barriers per tile and
+    keeps its operands in flight across them: a missing wait would show as run-to-run differences.  Forty launches of the
+    forward (BatchNorm partials included) and of the backward-data on the same operands must agree bit for bit, with
+    several tiles per workgroup."""
+    from agcn_amd import ops
+    dev = _gpu()
+    N, C, Cout, T, V = case
+    monkeypatch.setenv('AGCN_WS_SPLIT', '2')
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(N, C, T, V, generator=g).to(dev)
+    adj = (0.3 * torch.randn(N, 3, V, V, generator=g)).to(dev)
+    w = (torch.randn(Cout, 3 * C, generator=g) / np.sqrt(3 * C)).to(dev)
+    b = (0.1 * torch.randn(Cout, generator=g)).to(dev)
+    dy = torch.randn(N, Cout, T, V, generator=g).to(dev)
+    y0, s0 = ops.aggregate_project_fwd(x, adj, w, b, want_stats=True)
+    dx0 = ops.aggregate_project_bwd_data(dy, adj, w, tuple(x.shape), add1=x, mask1=x)
+    torch.cuda.synchronize()
+    for _ in range(40):
+        y, s = ops.aggregate_project_fwd(x, adj, w, b, want_stats=True)
+        dx = ops.aggregate_project_bwd_data(dy, adj, w, tuple(x.shape), add1=x, mask1=x)
+        assert torch.equal(y, y0) and torch.equal(s, s0)
+        assert torch.equal(dx, dx0)
