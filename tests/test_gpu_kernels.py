@@ -760,7 +760,8 @@ def test_ws_chain_multi_tile(case, monkeypatch):
     y_ref.backward(dy)
     xg, ag, wg, bg, dyg = [t.detach().float().to(dev) for t in (x, adj, wcat, bias, dy)]
     L = ops._L()
-    ws_mode = L.agcn_chain_mode().decode() == 'f16x3'      # (AGCN_GEMM=f32 / bf16 runs take the generic kernels)
+    # (AGCN_GEMM=f32 / bf16 runs take the generic kernels)
+    ws_mode = L.agcn_chain_mode().decode() == 'f16x3' and L.agcn_gemm_mode().decode() == 'bf16x6'
     if C >= 32:
         y, stats = ops.aggregate_project_fwd(xg, ag, wg, bg, want_stats=True)
         assert (not ws_mode) or 'gcn_ws_kernel' in L.agcn_last_kernel().decode(), L.agcn_last_kernel()
