@@ -183,10 +183,12 @@ __global__ void __launch_bounds__(NT, (TM * 16 + PD * 8 + 60 <= 128) ? 4 : 2) ad
     }
   }
 
-  if (track_amax) {                             // one atomicMax per wave (max is order-independent: deterministic)
+  if (track_amax) {
+    // max is order-independent (deterministic).  One atomic per WAVE at most, and none once the running maximum in memory
+    // has passed the wave's own (thousands of atomics on one address would serialise in L2)
 #pragma unroll
     for (int k = 32; k >= 1; k >>= 1) xmax = max(xmax, (unsigned)__shfl_xor((int)xmax, k));
-    if (lane == 0) atomicMax(a.x_absmax, xmax);
+    if (lane == 0 && xmax > __hip_atomic_load(a.x_absmax, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(a.x_absmax, xmax);
   }
   // bias of the rows this lane holds
   if (a.bias) {

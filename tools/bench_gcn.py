@@ -52,6 +52,16 @@ for name in layers:
         aggb = 3 * 2 * Cout * T * V * V * N
         us = timed(lambda: ops.aggregate_project_bwd_data(dy, adj, w, tuple(x.shape), add1=x, mask1=x))
         out.append(f'bwdx {us:7.0f} us {(proj + aggb) / us / 1e6:6.1f} TF')
+    if 'bwdf' in which and ops.fused_bwd_data_supported(C, Cout, V):   # as in training: fused 1x1 term + two masked residuals
+        K2 = 6 * (Cout // 4)
+        dtp = torch.randn(N, K2, T, V, generator=g).to(dev)
+        wab = (torch.randn(K2, C, 1, 1, generator=g) / K2 ** 0.5).to(dev)
+        bits = (torch.randint(0, 2 ** 31 - 1, ((N * C * T * V + 31) // 32,), generator=g, dtype=torch.int64).to(torch.int32)).to(dev)
+        aggb = 3 * 2 * Cout * T * V * V * N
+        amax = torch.full((1,), 4.0, device=dev)
+        us = timed(lambda: ops.aggregate_project_bwd_data(dy, adj, w, tuple(x.shape), add1=x, mask1=bits, add2=x, mask2=bits,
+                                                          dtp=dtp, wab=wab, dy_amax=amax, dtp_amax=amax))
+        out.append(f'bwdf {us:7.0f} us {(proj + aggb + 2.0 * K2 * C * T * V * N) / us / 1e6:6.1f} TF')
     if 'dadj' in which:
         L = ops._L(); ns = L.agcn_dadj_num_slots(C, V, T)
         dpart = torch.empty((N, 3, ns, V, V), device=dev)
