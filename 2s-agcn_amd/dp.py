@@ -41,11 +41,14 @@ def enable_sync_bn(model, world_size, group=None):
     return model
 
 
-def allreduce_gradients(flat_grad, world_size, async_op=False):
+def allreduce_gradients(flat_grad, world_size, async_op=False, force=False):
     """SUM all-reduce of (a slice of) the flat gradient buffer.  The caller applies 1/world_size.
     async_op: returns the work handle (None for world_size 1); with RCCL the collective runs on the communicator's own
-    stream and ``handle.wait()`` makes the compute stream wait for it."""
-    if world_size > 1:
+    stream and ``handle.wait()`` makes the compute stream wait for it.  force: issue the collective even in a group of
+    one rank (the one-GPU rehearsal of the multi-GPU schedule, bench.py --rehearse-dp)."""
+    if world_size > 1 or (force and dist.is_initialized()):
+        from . import ops as _ops
+        _ops.COLLECTIVES['grad'] += 1
         w = dist.all_reduce(flat_grad, op=dist.ReduceOp.SUM, async_op=async_op)
         return w if async_op else flat_grad
     return None if async_op else flat_grad
@@ -77,6 +80,6 @@ def allreduce_scalar(value, world_size, device):
 def allreduce_min_flag(flag, world_size, device):
     """True only if ``flag`` holds on EVERY rank (one tiny MIN all-reduce; used once, to agree on a static schedule)."""
     t = torch.tensor([1.0 if flag else 0.0], dtype=torch.float32, device=device)
-    if world_size > 1:
+    if world_size > 1 and dist.is_initialized():
         dist.all_reduce(t, op=dist.ReduceOp.MIN)
     return bool(t.item() > 0.5)

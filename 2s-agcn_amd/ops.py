@@ -605,8 +605,12 @@ def _colsum(slab, nslots, width):
     return out
 
 
+COLLECTIVES = {'bn': 0, 'grad': 0}      # diagnostic: collectives issued so far (bench.py reports them per step)
+
+
 def _allreduce_sum(t, sync):
     import torch.distributed as dist
+    COLLECTIVES['bn'] += 1
     dist.all_reduce(t, op=dist.ReduceOp.SUM, group=sync.group)
     return t
 

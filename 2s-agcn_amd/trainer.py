@@ -110,6 +110,7 @@ class TrainEngine:
         self._tail_static = None      # None: undecided (first step only probes); True / False: agreed by ALL ranks
         self._tail_probe = False      # what this rank's hook saw during the probing step
         self._pending = []            # async all-reduce handles of this step
+        self.rehearse = False         # True: take the multi-rank schedule (buckets, collectives) with a group of ONE rank
         self.early_buckets = 0        # how many steps sent their tail bucket from inside the backward (diagnostic)
         if world_size > 1:
             self._setup_overlap()
@@ -158,21 +159,22 @@ class TrainEngine:
                                "backward passed the cut module, although all ranks agreed on the two-bucket schedule "
                                "at the first step; the schedule is static (every rank must issue the same collectives)")
         off = self.fp.offsets[self._tail_lo]
-        self._pending.append(_dp.allreduce_gradients(self.fp.grad[off:], self.world_size, async_op=True))
+        self._pending.append(_dp.allreduce_gradients(self.fp.grad[off:], self.world_size, async_op=True, force=self.rehearse))
         self.early_buckets += 1
         return None
 
     def _finish_allreduce(self):
         if self._tail_lo is not None and self._tail_static is None:
             # first step: agree on the schedule (every rank must see its tail complete at the cut)
-            self._tail_static = bool(_dp.allreduce_min_flag(self._tail_probe, self.world_size, self.fp.grad.device))
+            self._tail_static = bool(_dp.allreduce_min_flag(self._tail_probe, max(self.world_size, 2 if self.rehearse else 1),
+                                                            self.fp.grad.device))
         if self._pending:             # tail bucket already in flight: only the head remains
             off = self.fp.offsets[self._tail_lo]
             self.fp.gather_grads(0, self._tail_lo)
-            self._pending.append(_dp.allreduce_gradients(self.fp.grad[:off], self.world_size, async_op=True))
+            self._pending.append(_dp.allreduce_gradients(self.fp.grad[:off], self.world_size, async_op=True, force=self.rehearse))
         else:
             self.fp.gather_grads()
-            self._pending.append(_dp.allreduce_gradients(self.fp.grad, self.world_size, async_op=True))
+            self._pending.append(_dp.allreduce_gradients(self.fp.grad, self.world_size, async_op=True, force=self.rehearse))
         for w in self._pending:
             if w is not None:
                 w.wait()
@@ -184,7 +186,7 @@ class TrainEngine:
         self.fp.detach_grads()
         self._pending = []
         loss.backward()
-        if self.world_size > 1:
+        if self.world_size > 1 or self.rehearse:
             self._finish_allreduce()      # RCCL over xGMI (SUM); the 1/world average is folded into the update
         else:
             self.fp.gather_grads()

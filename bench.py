@@ -148,6 +148,75 @@ def dominant_kernel_roofline(device, reps=10):
             "algorithmic_bytes_per_launch": 4.0 * 2 * N * C * T * V, "max_rel_err_vs_fp64": float(f"{err:.3g}")}
 
 
+def chain_kernel_roofline(device, reps=10):
+    """The aggregate+project chain (unit_gcn's `sum_i Wd_i (x . A^_i)`, reference agcn.py:103-105) at the l2-l4 shape
+    (N'=128, C=Cout=64, T=300, V=25), forward with BatchNorm partials, timed with HIP events on the launch stream with the
+    operand maximum supplied (as the model does).  Algorithmic work: aggregate 3*2*C*T*V*V + project
+    3*2*C*Cout*T*V FLOP per sample = 32.8 GFLOP, 491.5 MB.  Peak: f16x3 = 2500/3 TFLOP/s fp32-equivalent; HBM 8 TB/s."""
+    import agcn_amd  # noqa: F401
+    from agcn_amd import ops
+    L = ops._L()
+    N, C, T, V = 128, 64, 300, 25
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(N, C, T, V, generator=g).to(device)
+    adj = (0.2 * torch.randn(N, 3, V, V, generator=g)).to(device)
+    w = (torch.randn(C, 3 * C, generator=g) / (3 * C) ** 0.5).to(device)
+    b = torch.zeros(C, device=device)
+    amax = x.abs().max().reshape(1).contiguous()
+    for _ in range(2):
+        ops.aggregate_project_fwd(x, adj, w, b, want_stats=True, x_amax=amax)
+    kernel = L.agcn_last_kernel().decode()
+    torch.cuda.synchronize()
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    s.record()
+    for _ in range(reps):
+        ops.aggregate_project_fwd(x, adj, w, b, want_stats=True, x_amax=amax)
+    e.record()
+    torch.cuda.synchronize()
+    ms = s.elapsed_time(e) / reps          # includes the ~5 us weight-pack launch of every call
+    flops = N * (3 * 2.0 * C * T * V * V + 3 * 2.0 * C * C * T * V)
+    nbytes = 4.0 * 2 * N * C * T * V
+    chain_mode = L.agcn_chain_mode().decode()
+    peak = round(PEAK_BF16_MFMA_TFLOPS / 3, 1) if chain_mode == 'f16x3' else PEAK_FP32_MFMA_TFLOPS
+    t_mfma, t_hbm = flops / (peak * 1e12) * 1e3, nbytes / 8e12 * 1e3
+    return {"kernel": kernel, "what": "aggregate+project chain forward, l2-l4 shape (N'=128, C=64, T=300, V=25)",
+            "ms_per_launch": round(ms, 4), "TFLOPs": round(flops / ms / 1e9, 2), "GBps": round(nbytes / ms / 1e6, 1),
+            "bound": "hbm" if t_hbm > t_mfma else "mfma", "frac": round(max(t_mfma, t_hbm) / ms, 4),
+            "frac_of_hbm": round(t_hbm / ms, 4), "frac_of_mfma_f16x3": round(t_mfma / ms, 4),
+            "flops_per_launch": flops, "algorithmic_bytes_per_launch": nbytes}
+
+
+def exact_f32_value(args):
+    """clips/s of the SAME step with every contraction on exact-f32 MFMA (AGCN_GEMM=f32), for context next to the
+    split-arithmetic headline: AGCN_GEMM is read once per process, so this is a child process."""
+    import subprocess
+    env = dict(os.environ, AGCN_GEMM='f32')
+    cmd = [sys.executable, os.path.abspath(__file__), '--steps', '5', '--warmup', '2', '--no-cpu-baseline', '--no-roofline',
+           '--workload', args.workload, '--batch', str(args.batch)]
+    try:
+        r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+        return json.loads(r.stdout.strip().splitlines()[-1])['value']
+    except Exception as ex:     # noqa: BLE001 -- context only; never fails the benchmark line
+        print(f"[bench] exact-f32 context run failed: {ex}", file=sys.stderr, flush=True)
+        return None
+
+
+def top_profiled_kernel():
+    """The kernel with the largest share of the step in the committed rocprofv3 profile of this round (profiles/r03_*)."""
+    import glob
+    import re
+    files = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*_kernel_stats.txt')))
+    if not files:
+        return None
+    with open(files[-1]) as f:
+        for ln in f:
+            m = re.match(r'\s*([\d.]+)%\s+calls/step\s+([\d.]+)\s+avg\s+([\d.]+) us\s+ms/step\s+([\d.]+)\s+(.*)', ln)
+            if m:
+                return {"kernel": m.group(5).strip(), "share_of_step_pct": float(m.group(1)), "calls_per_step": float(m.group(2)),
+                        "avg_us": float(m.group(3)), "ms_per_step": float(m.group(4)), "profile": os.path.basename(files[-1])}
+    return None
+
+
 GCN_LAYER_SHAPES = [  # (name, C, Cout, T) at N'=128, V=25: the distinct unit_gcn shapes of configs[1] (SURVEY 8d table)
     ('l1', 3, 64, 300), ('l2-4', 64, 64, 300), ('l5', 64, 128, 300), ('l6-7', 128, 128, 150),
     ('l8', 128, 256, 150), ('l9-10', 256, 256, 75)]
@@ -273,6 +342,57 @@ def cpu_baseline(batches=(1, 8), warmups=2, reps=5):
                       f"; {cores} threads on {model}, torch {torch.__version__}"}
 
 
+def dp_rehearsal(args, device, wl, plain_ms):
+    """Multi-GPU schedule on ONE GPU: a real RCCL process group of one rank, every BatchNorm stage forced onto the
+    synchronised-statistics path (ops.sync_of), TrainEngine on its two-bucket overlapped gradient all-reduce.  Every
+    collective is the identity, so what is measured is their count and the time they add to the step (launch + RCCL
+    kernel latency + the stream synchronisation around them): the communication cost a multi-GPU step cannot hide."""
+    import agcn_amd  # noqa: F401
+    from agcn_amd import ops
+    from agcn_amd.trainer import TrainEngine, synthetic_batch
+    os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+    os.environ.setdefault('MASTER_PORT', '29544')
+    # RCCL prints its version banner on stdout at the first collective: keep stdout for the one JSON line
+    sys.stdout.flush()
+    saved_fd = os.dup(1)
+    os.dup2(2, 1)
+    dist.init_process_group(backend='nccl', rank=0, world_size=1, device_id=device)
+    orig = ops.sync_of
+    ops.sync_of = lambda bn: ops.SyncBN(1, None)
+    try:
+        torch.manual_seed(0)
+        model = build_model(args.workload)
+        randomize_like_training(model, seed=0)
+        model.to(device)
+        eng = TrainEngine(model, base_lr=0.1, momentum=0.9, nesterov=True, weight_decay=1e-4, max_grad_norm=1.0, world_size=1)
+        eng.rehearse = True
+        eng._setup_overlap()
+        data, label = synthetic_batch(args.batch, num_point=wl[2], num_class=wl[1], seed=1234, device=device)
+        for _ in range(max(3, args.warmup)):
+            eng.train_step(data, label)
+        torch.cuda.synchronize()
+        c0 = dict(ops.COLLECTIVES)
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            eng.train_step(data, label)
+        torch.cuda.synchronize()
+        ms = (time.perf_counter() - t0) / args.steps * 1e3
+        per = {k: (ops.COLLECTIVES[k] - c0[k]) / args.steps for k in c0}
+    finally:
+        ops.sync_of = orig
+        dist.destroy_process_group()
+        sys.stdout.flush()
+        os.dup2(saved_fd, 1)
+        os.close(saved_fd)
+    return {"world": 1, "backend": "nccl (RCCL)", "collectives_per_step": {"batchnorm_statistics": per['bn'],
+                                                                           "gradient_buckets": per['grad']},
+            "ms_per_step_with_collectives": round(ms, 3), "ms_per_step_plain": round(plain_ms, 3),
+            "exposed_ms_per_step": round(ms - plain_ms, 3),
+            "note": "one rank: every collective is the identity; the difference is launch + RCCL latency + the "
+                    "synchronisation around 2 collectives per unit stage and direction (a stage's statistics depend on "
+                    "the previous stage's output, so they cannot be merged further) and 2 gradient buckets"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -286,6 +406,10 @@ def main():
                          'runs -- the semantics of the reference\'s only multi-process path (DDP + SyncBatchNorm, '
                          'utils/processor.py:295), so the multi-GPU number pays the per-layer BN collectives the '
                          'reference pays; off: per-replica statistics (its nn.DataParallel path, :336-343)')
+    ap.add_argument('--rehearse-dp', action='store_true',
+                    help='one-GPU rehearsal of the multi-GPU schedule: a real RCCL group of ONE rank, every BatchNorm stage on '
+                         'the synchronised path, the two-bucket gradient all-reduce; reports collectives per step and the '
+                         'time they add to the step (dp_rehearsal)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-roofline', action='store_true')
     args = ap.parse_args()
@@ -381,8 +505,14 @@ def main():
         }
         if world == 1 and not args.no_roofline and args.workload in ('ntu_agcn', 'ntu_aagcn', 'ntu_aagcn_bf16'):
             out["roofline"] = dominant_kernel_roofline(device)
+            out["roofline"]["top_profiled_kernel"] = top_profiled_kernel()
+            out["chain_kernel"] = chain_kernel_roofline(device)
             out["unit_gcn_fwd"] = unit_gcn_forward_roofline(device)
+            if gemm_mode == 'bf16x6' and args.workload == 'ntu_agcn':
+                out["exact_f32_value"] = exact_f32_value(args)     # same step, every contraction on exact-f32 MFMA
             print("[bench] roofline done", file=sys.stderr, flush=True)
+        if world == 1 and (args.rehearse_dp or (not args.no_roofline and args.workload == 'ntu_agcn')):
+            out["dp_rehearsal"] = dp_rehearsal(args, device, wl, dt / args.steps * 1e3)
         if world == 1 and not args.no_cpu_baseline and args.workload == 'ntu_agcn':
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out), flush=True)
