@@ -118,9 +118,9 @@ __global__ void __launch_bounds__(256) chain_pack_kernel(const ChainPackArgs p) 
 // VS >= (V+1)/2 aggregation steps (13: NTU V=25, 9: Kinetics V=18, 16: any V <= 32; surplus steps multiply zero rows)
 // NW waves per workgroup = frames per workgroup tile (one frame per wave)
 // F16 (with VS == 0): both contractions on f16x3 (split_f16.h) instead of bf16x6: two fp16 planes per operand, three
-// products; the staged source is multiplied by the power of two that brings max(|in|, |in2|) into [2^8, 2^9) before it
-// is split (so that G = x . A^ stays inside fp16's range for column sums of |A^| up to 2^7) and the accumulators by its
-// inverse in the epilogue.
+// products; the staged source is multiplied by the power of two that brings max(|in|, |in2|) into [2^2, 2^3)
+// (F16_ADJ_TARGET) before it is split (so that G = x . A^ stays inside fp16's range for column sums of |A^| up to 2^13)
+// and the accumulators by its inverse in the epilogue.
 template <int TM, int VS, int NW, bool F16 = false>
 __global__ void __launch_bounds__(NW * 64, 2) gcn_chain_kernel(const ChainArgs a) {
   static_assert(!F16 || VS == 0, "the f16x3 chain runs the aggregation on split MFMA too");
@@ -167,7 +167,7 @@ __global__ void __launch_bounds__(NW * 64, 2) gcn_chain_kernel(const ChainArgs a
   if constexpr (F16) {
     float mx = a.in_absmax ? *a.in_absmax : 0.f;
     if (a.in2_absmax) mx = fmaxf(mx, *a.in2_absmax);
-    f16_range_scale_of<8>(mx, rs_s, rs_inv);
+    f16_range_scale_of<F16_ADJ_TARGET>(mx, rs_s, rs_inv);
   }
 
   // bias of this row block, beyond everything the epilogue tile overwrites
@@ -642,7 +642,7 @@ gcn_ws_kernel(const ChainArgs a, const WsGeom g) {
   {
     float mx = a.in_absmax ? *a.in_absmax : 0.f;
     if (a.in2_absmax) mx = fmaxf(mx, *a.in2_absmax);
-    f16_range_scale_of<8>(mx, rs_s, rs_inv);
+    f16_range_scale_of<F16_ADJ_TARGET>(mx, rs_s, rs_inv);
   }
   // ---- row-store machinery (store waves when ROLES, else the matrix waves themselves) ----
   // A store wave owns whole rows of the O tile: row r = sw + NSW * u, lane <-> 16-byte granule (floats 4 lane .. 4 lane + 3)

@@ -331,7 +331,7 @@ __global__ void __launch_bounds__((NWC + NWP) * 64, (NWC + NWP) / 4) wgrad_pc_ke
   float s_dy = 1.f, inv_dy = 1.f, s_x = 1.f, inv_x = 1.f;
   if constexpr (F16) {
     f16_range_scale_of<14>(*a.dy_absmax, s_dy, inv_dy);
-    f16_range_scale_of<8>(*a.in_absmax, s_x, inv_x);
+    f16_range_scale_of<F16_ADJ_TARGET>(*a.in_absmax, s_x, inv_x);
   }
   // VS == 0: the aggregation chain runs on split-bf16 MFMA (12 MFMAs of 32 cycles for K = 32 joints instead of VS
   // exact-f32 steps of 64 cycles): adjacencies kept as bf16 planes [subset][plane][ks][h][v][8 u] (gcn_chain.hip)

@@ -826,3 +826,35 @@ def test_ws_chain_repeats_bit_for_bit(case, monkeypatch):
         dx = ops.aggregate_project_bwd_data(dy, adj, w, tuple(x.shape), add1=x, mask1=x)
         assert torch.equal(y, y0) and torch.equal(s, s0)
         assert torch.equal(dx, dx0)
+
+
+@pytest.mark.parametrize('case', [(2, 64, 64, 24, 25), (2, 256, 256, 9, 25), (2, 128, 128, 16, 18)])
+def test_f16x3_adjacency_headroom(case):
+    """The f16x3 graph chain splits G = x . A^ (not x), so its range scale must leave room for the adjacency: PA is an
+    unconstrained trained parameter.  With column / row sums of |A^| around 1500 (round 2's scale overflowed fp16 beyond
+    128) the forward, the backward-data and the projection's weight gradient still match fp64 (persistent 64- and
+    128-channel kernels and the tile-per-workgroup one at 256 channels)."""
+    from agcn_amd import ops
+    dev = _gpu()
+    N, C, Cout, T, V = case
+    g = torch.Generator().manual_seed(41 + C)
+    x = rnd(g, N, C, T, V).requires_grad_(True)
+    adj = rnd(g, N, 3, V, V, scale=75.0)
+    assert float(adj.abs().sum(-2).max()) > 1000 and float(adj.abs().sum(-1).max()) > 1000
+    wcat = rnd(g, Cout, 3 * C, scale=1.0 / np.sqrt(3 * C)).requires_grad_(True)
+    bias = rnd(g, Cout, scale=0.1)
+    y_ref = _gcn_ref(x, adj, wcat, bias)
+    dy = rnd(g, *y_ref.shape)
+    y_ref.backward(dy)
+    xg, ag, wg, bg, dyg = [t.detach().float().to(dev) for t in (x, adj, wcat, bias, dy)]
+    y, _ = ops.aggregate_project_fwd(xg, ag, wg, bg, want_stats=True)
+    assert torch.isfinite(y).all()
+    assert rel(y, y_ref) < TOL
+    dx = ops.aggregate_project_bwd_data(dyg, ag, wg, tuple(x.shape))
+    assert torch.isfinite(dx).all()
+    assert rel(dx, x.grad) < TOL
+    amax_x = xg.abs().max().reshape(1)
+    amax_dy = dyg.abs().max().reshape(1)
+    dw = ops.project_bwd_weight(dyg, xg, ag, Cout, amax_dy, amax_x)       # (both maxima: the f16x3 weight-gradient kernel)
+    assert torch.isfinite(dw).all()
+    assert rel(dw, wcat.grad) < TOL
