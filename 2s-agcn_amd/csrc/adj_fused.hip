@@ -15,6 +15,7 @@
 // register ring PD chunks deep: one barrier per chunk, the global loads of chunks k+2..k+PD in flight during chunk k.
 // Phase 2 works on 16-channel groups (16 theta + 16 phi rows), so its LDS tile is 33 KB whatever Ci is.
 #include "agcn_common.h"
+#include "split_f16.h"
 #include "split_bf16.h"
 
 namespace {
@@ -448,26 +449,49 @@ int agcn_adjacency_fused_supported(int C, int Ci, int T, int V) { return af_supp
 size_t agcn_adjacency_fused_workspace(int C, int Ci) {
   int tm, nsub;
   if (!af_shape(Ci, tm, nsub)) return 256;
-  return af_geometry(C, 1, 25, tm * 32, nsub).pack_bytes + 256;
+  const size_t own = af_geometry(C, 1, 25, tm * 32, nsub).pack_bytes + 256, ws = agcn_adj_ws_workspace(C, Ci) + 256;
+  return own > ws ? own : ws;
 }
 
 int agcn_adjacency_fused_fwd_ex(const float* x, const float* wab, const float* bab, const float* A, const float* PA,
                                 const float* alpha, float* tp_out, float* spart, float* P, float* adj, float* x_absmax_out,
-                                void* workspace, size_t workspace_bytes, int N, int C, int Ci, int T, int V, void* stream);
+                                const float* x_absmax_in, void* workspace, size_t workspace_bytes, int N, int C, int Ci, int T,
+                                int V, void* stream);
 int agcn_adjacency_fused_fwd(const float* x, const float* wab, const float* bab, const float* A, const float* PA,
                              const float* alpha, float* tp_out, float* spart, float* P, float* adj, void* workspace,
                              size_t workspace_bytes, int N, int C, int Ci, int T, int V, void* stream) {
-  return agcn_adjacency_fused_fwd_ex(x, wab, bab, A, PA, alpha, tp_out, spart, P, adj, nullptr, workspace, workspace_bytes,
-                                     N, C, Ci, T, V, stream);
+  return agcn_adjacency_fused_fwd_ex(x, wab, bab, A, PA, alpha, tp_out, spart, P, adj, nullptr, nullptr, workspace,
+                                     workspace_bytes, N, C, Ci, T, V, stream);
 }
-// x_absmax_out (optional, 4 bytes): receives max |x|, a by-product of the pass (for the f16x3 chain that reads x next)
+// x_absmax_out (optional, 4 bytes): receives max |x|, a by-product of the pass (for the f16x3 chain that reads x next).
+// x_absmax_in (optional): max |x| when the producer of x already took it.  The layers whose stacked weights fit in LDS
+// (adj_ws.hip) run on the persistent f16x3 kernel, which needs the maximum up front: taken by a reduction pass when absent.
 int agcn_adjacency_fused_fwd_ex(const float* x, const float* wab, const float* bab, const float* A, const float* PA,
                                 const float* alpha, float* tp_out, float* spart, float* P, float* adj, float* x_absmax_out,
-                                void* workspace, size_t workspace_bytes, int N, int C, int Ci, int T, int V, void* stream) {
+                                const float* x_absmax_in, void* workspace, size_t workspace_bytes, int N, int C, int Ci, int T,
+                                int V, void* stream) {
   if (!x || !wab || !PA || !spart || !P || !adj || !workspace || N <= 0 || C <= 0 || Ci <= 0 || T <= 0 || V <= 0 ||
       V > 32)
     return AGCN_ERR_ARG;
   if (!af_supported(C, Ci, T, V)) return AGCN_ERR_UNSUPPORTED;
+  if (agcn_adj_ws_supported(N, C, Ci, T, V)) {
+    const size_t img = agcn_adj_ws_workspace(C, Ci);
+    if (workspace_bytes < img + 16) return AGCN_ERR_WORKSPACE;
+    hipStream_t s = (hipStream_t)stream;
+    const float* amax = x_absmax_in;
+    if (!amax) {
+      float* slot = x_absmax_out ? x_absmax_out : reinterpret_cast<float*>(static_cast<char*>(workspace) + img);
+      if (int rc = agcn_launch_absmax(x, (long)N * C * T * V, reinterpret_cast<unsigned*>(slot), s)) return rc;
+      amax = slot;
+    } else if (x_absmax_out && x_absmax_out != x_absmax_in) {
+      if (hipMemcpyAsync(x_absmax_out, x_absmax_in, 4, hipMemcpyDeviceToDevice, s) != hipSuccess) return AGCN_ERR_ARG;
+    }
+    const int tt = 256 / V > T ? T : 256 / V, slots = (T + tt - 1) / tt;
+    int nused = 0;
+    if (int rc = agcn_adj_ws_scores(x, wab, bab, tp_out, spart, slots, &nused, amax, workspace, img, N, C, Ci, T, V, s))
+      return rc;
+    return agcn_adj_finalize(spart, A, PA, alpha, P, adj, N, Ci, T, V, s, nused);
+  }
   if (x_absmax_out && hipMemsetAsync(x_absmax_out, 0, 4, (hipStream_t)stream) != hipSuccess) return AGCN_ERR_ARG;
   AfArgs a = {};
   a.x_absmax = reinterpret_cast<unsigned*>(x_absmax_out);

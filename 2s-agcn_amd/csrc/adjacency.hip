@@ -92,7 +92,7 @@ scores_fwd_kernel(const float* __restrict__ tp, float* __restrict__ spart, int N
 __global__ void __launch_bounds__(256)
 adj_finalize_kernel(const float* __restrict__ spart, const float* __restrict__ A, const float* __restrict__ PA,
                     const float* __restrict__ alpha, float* __restrict__ Pout, float* __restrict__ adj, int V,
-                    int ntiles, float inv_k) {
+                    int ntiles, int nused, float inv_k) {
   __shared__ float S[32 * 32];
   const int ni = blockIdx.x, i = ni % 3;
   const int VV = V * V, lane = threadIdx.x;
@@ -100,7 +100,7 @@ adj_finalize_kernel(const float* __restrict__ spart, const float* __restrict__ A
   for (int e = lane; e < VV; e += 256) {
     float s = 0.f;
 #pragma unroll 8
-    for (int t = 0; t < ntiles; ++t) s += src[(long)t * VV + e];     // fixed order; 8 loads in flight
+    for (int t = 0; t < nused; ++t) s += src[(long)t * VV + e];      // fixed order; 8 loads in flight
     S[e] = s * inv_k;
   }
   __syncthreads();
@@ -397,10 +397,12 @@ inline int sc_tile_frames(int V, int T) {
 
 // sum the (sample, subset, tile) score slabs, scale by 1/(Ci*T), column softmax, add the static graph terms
 // (shared with adj_fused.hip)
+// nused: how many of the ntiles slots of each (sample, subset) hold partials (-1: all of them)
 int agcn_adj_finalize(const float* spart, const float* A, const float* PA, const float* alpha, float* P, float* adj,
-                      int N, int Ci, int T, int V, hipStream_t s) {
+                      int N, int Ci, int T, int V, hipStream_t s, int nused) {
   const int tt = sc_tile_frames(V, T), ntiles = (T + tt - 1) / tt;
-  hipLaunchKernelGGL(adj_finalize_kernel, dim3(N * 3), dim3(256), 0, s, spart, A, PA, alpha, P, adj, V, ntiles,
+  if (nused < 0 || nused > ntiles) nused = ntiles;
+  hipLaunchKernelGGL(adj_finalize_kernel, dim3(N * 3), dim3(256), 0, s, spart, A, PA, alpha, P, adj, V, ntiles, nused,
                      1.0f / ((float)Ci * (float)T));
   return agcn_check_launch();
 }

@@ -52,7 +52,14 @@ extern "C" int agcn_colsum(const float* X, int nslots, int W, void* scratch, flo
 
 // adjacency.hip: slab sum + 1/K + column softmax + graph terms (also the tail of adj_fused.hip's forward)
 int agcn_adj_finalize(const float* spart, const float* A, const float* PA, const float* alpha, float* P, float* adj,
-                      int N, int Ci, int T, int V, hipStream_t s);
+                      int N, int Ci, int T, int V, hipStream_t s, int nused = -1);
+
+// persistent weight-stationary forward of the adjacency scores (adj_ws.hip)
+bool agcn_adj_ws_supported(int N, int C, int Ci, int T, int V);
+size_t agcn_adj_ws_workspace(int C, int Ci);
+int agcn_adj_ws_scores(const float* x, const float* wab, const float* bab, float* tp_out, float* spart, int slots,
+                       int* nslots_used, const float* x_absmax, void* ws, size_t ws_bytes, int N, int C, int Ci, int T, int V,
+                       hipStream_t s);
 
 // split-bf16 temporal convolution (conv_gemm_bf16.hip); npl: 3 = bf16x6 (fp32-equivalent), 2 = bf16x3
 size_t agcn_bf16_conv_workspace(int Cin, int Cout, int T, int V, int stride);

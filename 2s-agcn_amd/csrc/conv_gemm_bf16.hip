@@ -103,7 +103,7 @@ __global__ void __launch_bounds__(256) pack_weights_bf16_kernel(const BfPackArgs
       v[q] = (m < p.M && kc < p.Kinner) ? p.w[(long)m * p.sa_m + (long)kc * p.sa_c + gt] : 0.f;
     }
     unsigned ph, pm, pl = 0;
-    if constexpr (F16) split_pair_f16(v[0], v[1], ph, pm);
+    if constexpr (F16) split_pair_f16(v[0] * F16_W_SCALE, v[1] * F16_W_SCALE, ph, pm);
     else split_pair(v[0], v[1], ph, pm, pl);
     const int o = ((tap * 2 + h) * BM + ml) * 8 + j;
     *reinterpret_cast<unsigned*>(dst + 0 * PER_PLANE + o) = ph;
@@ -141,7 +141,7 @@ __global__ void __launch_bounds__(NT, (TAPS == 1 && TM == 2 && TN == 1) ? 4 : 2)
   const int WL = a.FW * V, WLR = a.WLR;
   const int g0 = f0 * V;
   float rs_s = 1.f, rs_inv = 1.f;                      // f16x3 range scale of the activations
-  if constexpr (F16) f16_range_scale(a.in_absmax, rs_s, rs_inv);
+  if constexpr (F16) { f16_range_scale(a.in_absmax, rs_s, rs_inv); rs_inv *= F16_W_INV; }
 
   int boff[TN];                           // this wave's TN x 32 positions
 #pragma unroll
@@ -354,7 +354,7 @@ __global__ void __launch_bounds__((8 + NWP) * 64, 3) conv_pc_kernel(const BfArgs
   const int nchunks = a.nchunks;
   const int G = nchunks * TAPS;
   float rs_s = 1.f, rs_inv = 1.f;                      // f16x3 range scale of the activations
-  if constexpr (F16) f16_range_scale(a.in_absmax, rs_s, rs_inv);
+  if constexpr (F16) { f16_range_scale(a.in_absmax, rs_s, rs_inv); rs_inv *= F16_W_INV; }
 
   float* bias_s = reinterpret_cast<float*>(smem + a.off_bias);
   for (int e = threadIdx.x; e < BM; e += NTALL) bias_s[e] = (a.bias && m0 + e < a.M) ? a.bias[m0 + e] : 0.f;
@@ -580,7 +580,7 @@ __global__ void __launch_bounds__(256) pack_weights_slots_kernel(const BfPackArg
       v[q] = (m < p.M && kc < p.Kinner) ? p.w[(long)m * p.sa_m + (long)kc * p.sa_c + gt] : 0.f;
     }
     unsigned ph, pm, pl = 0;
-    if constexpr (F16) split_pair_f16(v[0], v[1], ph, pm);
+    if constexpr (F16) split_pair_f16(v[0] * F16_W_SCALE, v[1] * F16_W_SCALE, ph, pm);
     else split_pair(v[0], v[1], ph, pm, pl);
     const int o = (h * BM + ml) * 8 + j;
     *reinterpret_cast<unsigned*>(dst + 0 * PLANE + o) = ph;

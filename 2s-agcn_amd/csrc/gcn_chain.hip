@@ -106,7 +106,7 @@ __global__ void __launch_bounds__(256) chain_pack_kernel(const ChainPackArgs p) 
       v[q] = (m < p.M && c < p.K) ? p.w[(long)m * p.sa_m + (long)i * p.sa_i + (long)c * p.sa_c] : 0.f;
     }
     unsigned ph, pm, pl = 0;
-    if constexpr (F16) split_pair_f16(v[0], v[1], ph, pm);
+    if constexpr (F16) split_pair_f16(v[0] * F16_W_SCALE, v[1] * F16_W_SCALE, ph, pm);
     else split_pair(v[0], v[1], ph, pm, pl);
     const int o = ((hf * TM + tm) * 64 + lane) * 8 + 2 * e2;
     *reinterpret_cast<unsigned*>(dst + 0 * PER_PLANE + o) = ph;
@@ -142,8 +142,8 @@ __global__ void __launch_bounds__(NW * 64, 2) gcn_chain_kernel(const ChainArgs a
   constexpr int ADJ_BYTES = BCH ? 3 * PL * 2 * 2 * 32 * 16 : 3 * 32 * 32 * 4;
   float* adjp = reinterpret_cast<float*>(smem);                       // [3][32][32] (f32 chain)
   unsigned char* adjq = smem;                                         // bf16 planes (split chain)
-  float* xb = reinterpret_cast<float*>(smem + ADJ_BYTES);             // [CB][XP] (+ 8 floats of slack when BCH)
-  const int xb_bytes = ((CB * a.XP * 4 + (BCH ? 32 : 0) + 15) & ~15);
+  float* xb = reinterpret_cast<float*>(smem + ADJ_BYTES);             // [CB][XP] (+ 32 floats of slack when BCH)
+  const int xb_bytes = ((CB * a.XP * 4 + (BCH ? 128 : 0) + 15) & ~15);
   unsigned char* abuf = smem + ADJ_BYTES + xb_bytes;                  // [2][A_IMG]
 
   const int tid = threadIdx.x, lane = tid & 63;
@@ -168,6 +168,7 @@ __global__ void __launch_bounds__(NW * 64, 2) gcn_chain_kernel(const ChainArgs a
     float mx = a.in_absmax ? *a.in_absmax : 0.f;
     if (a.in2_absmax) mx = fmaxf(mx, *a.in2_absmax);
     f16_range_scale_of<F16_ADJ_TARGET>(mx, rs_s, rs_inv);
+    rs_inv *= F16_W_INV;                               // (the packed weights carry F16_W_SCALE)
   }
 
   // bias of this row block, beyond everything the epilogue tile overwrites
@@ -206,7 +207,9 @@ __global__ void __launch_bounds__(NW * 64, 2) gcn_chain_kernel(const ChainArgs a
       *reinterpret_cast<unsigned*>(adjq + (i * PL + 1) * 2048 + o) = p1;
       if constexpr (!F16) *reinterpret_cast<unsigned*>(adjq + (i * PL + 2) * 2048 + o) = p2;
     }
-    if (tid < 8) xb[CB * XP + tid] = 0.f;                            // slack behind the last chunk row
+    // slack behind the last chunk row: the last frame's 32-joint fragment of the last row runs up to 32 - V floats past it
+    // (they meet zero rows of the adjacency, but must be finite: stale LDS bits can be NaN patterns)
+    if (tid < 32) xb[CB * XP + tid] = 0.f;
   }
 
   f32x16 acc[TM];
@@ -643,6 +646,7 @@ gcn_ws_kernel(const ChainArgs a, const WsGeom g) {
     float mx = a.in_absmax ? *a.in_absmax : 0.f;
     if (a.in2_absmax) mx = fmaxf(mx, *a.in2_absmax);
     f16_range_scale_of<F16_ADJ_TARGET>(mx, rs_s, rs_inv);
+    rs_inv *= F16_W_INV;                               // (the packed weights carry F16_W_SCALE)
   }
   // ---- row-store machinery (store waves when ROLES, else the matrix waves themselves) ----
   // A store wave owns whole rows of the O tile: row r = sw + NSW * u, lane <-> 16-byte granule (floats 4 lane .. 4 lane + 3)
@@ -1108,7 +1112,7 @@ ChainGeom chain_geometry(int V, int T, int M, int K, bool bch = false, int plane
   g.nmb = (M + BM - 1) / BM;
   g.XP = (FT * V) | 1;
   const size_t a_img = (size_t)planes * 2 * TM * 1024;
-  const size_t xb_bytes = ((size_t)CB * g.XP * 4 + (bch ? 32 : 0) + 15) & ~(size_t)15;
+  const size_t xb_bytes = ((size_t)CB * g.XP * 4 + (bch ? 128 : 0) + 15) & ~(size_t)15;
   g.smem_bytes = (bch ? (size_t)3 * planes * 2 * 2 * 32 * 16 : (size_t)3 * 32 * 32 * 4) + xb_bytes + 2 * a_img;
   const size_t epi_bytes = (size_t)BM * ((FT * V) | 1) * 4 + (size_t)NW * 64 * 2 * 4;
   if (epi_bytes > g.smem_bytes) g.smem_bytes = epi_bytes;
@@ -1328,7 +1332,7 @@ __global__ void __launch_bounds__(256) dadj_pack_kernel(const DadjPackArgs p) {
       v[q] = (m < p.C3 && o < p.Cout) ? p.w[(long)o * p.C3 + m] : 0.f;
     }
     unsigned ph, pm, pl = 0;
-    if constexpr (F16) split_pair_f16(v[0], v[1], ph, pm);
+    if constexpr (F16) split_pair_f16(v[0] * F16_W_SCALE, v[1] * F16_W_SCALE, ph, pm);
     else split_pair(v[0], v[1], ph, pm, pl);
     const int o2 = ((ks * TM + tm) * 64 + lane) * 8 + 2 * e2;
     *reinterpret_cast<unsigned*>(dst + 0 * PER_PLANE + o2) = ph;
@@ -1352,7 +1356,7 @@ __global__ void __launch_bounds__(NW * 64, 2) gcn_dadj_chain_kernel(const DadjAr
   const int PT = FT * V;                               // positions of the frame tile
   const int B_IMG = PL * 4 * PT * 16;                  // bytes: [plane][ks][h][pos][8]
   float rs_s = 1.f, rs_inv = 1.f;
-  if constexpr (F16) f16_range_scale(a.dy_absmax, rs_s, rs_inv);
+  if constexpr (F16) { f16_range_scale(a.dy_absmax, rs_s, rs_inv); rs_inv *= F16_W_INV; }
   unsigned char* abuf = smem;                          // [2][A_IMG]
   unsigned char* bbuf = smem + 2 * A_IMG;              // [2][B_IMG]
 

@@ -45,6 +45,14 @@ __device__ __forceinline__ void split_pair_f16_mix(float a, float b, unsigned& p
 // overflow to Inf and the loss turns NaN (visible, not silent); tests/test_gpu_kernels.py::test_f16x3_adjacency_headroom.
 constexpr int F16_ADJ_TARGET = 2;
 
+// WEIGHTS are split after a multiplication by the fixed power of two F16_W_SCALE, undone on the accumulators (both exact):
+// the residual plane of a weight w is (w - fp16(w)) ~ 2^-11 |w|, a normal fp16 only for |w| >= 2^-3 -- below that its
+// absolute error is half a subnormal step (2^-25), e.g. 5e-6 RELATIVE at the reference's conv_d initialisation of l8..l10
+// (std 0.0032), ten times an fp32 GEMM's own rounding (emulated: tools/split_numerics.py).  With the pre-scale the
+// threshold drops to |w| >= 2^-11 and the floor to 2^-33; weights up to 255 fit (|w| >= 256 -> Inf -> NaN loss, visible).
+// No measurement pass: trained convolution weights of this network sit between 1e-4 and O(1).
+constexpr float F16_W_SCALE = 256.f, F16_W_INV = 1.f / 256.f;
+
 template <int TARGET = 14>
 __device__ __forceinline__ void f16_range_scale_of(float m, float& s, float& inv) {
   s = 1.f; inv = 1.f;

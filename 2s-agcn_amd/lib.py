@@ -66,7 +66,7 @@ SIGNATURES = {
     "agcn_adjacency_fused_supported": (_I, [_I, _I, _I, _I]),
     "agcn_adjacency_fused_workspace": (_Z, [_I, _I]),
     "agcn_adjacency_fused_fwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _Z, _I, _I, _I, _I, _I, _P]),
-    "agcn_adjacency_fused_fwd_ex": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _Z, _I, _I, _I, _I, _I, _P]),
+    "agcn_adjacency_fused_fwd_ex": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _Z, _I, _I, _I, _I, _I, _P]),
     "agcn_adjacency_fused_bwd_scores": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _Z, _I, _I, _I, _I, _I, _P]),
     "agcn_adjacency_bwd_softmax": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
     "agcn_adjacency_bwd_scores": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),

@@ -196,10 +196,11 @@ def adjacency_recompute():
     return os.environ.get('AGCN_ADJ_RECOMPUTE', '0') == '1'
 
 
-def adjacency_fused_fwd(x, wab, bab, A, PA, alpha=None, keep_tp=False, x_amax_out=None):
+def adjacency_fused_fwd(x, wab, bab, A, PA, alpha=None, keep_tp=False, x_amax_out=None, x_amax=None):
     """P, adj straight from x: [theta;phi] = wab.x + bab is formed and reduced on chip (no tp round trip); wab
     (6Ci, C[,1,1]).  keep_tp: also return theta/phi, written once as a by-product (never re-read by the forward).
-    x_amax_out: optional 1-element tensor that receives max |x| (the pass reads all of x anyway)."""
+    x_amax_out: optional 1-element tensor that receives max |x| (the pass reads all of x anyway); x_amax: the same
+    scalar where the producer of x already took it."""
     N, C, T, V = x.shape
     Ci = wab.shape[0] // 6
     tp = _empty((N, 6 * Ci, T, V), x) if keep_tp else None
@@ -211,8 +212,8 @@ def adjacency_fused_fwd(x, wab, bab, A, PA, alpha=None, keep_tp=False, x_amax_ou
     ws = _ws(nb, x)
     _lib.check(_L().agcn_adjacency_fused_fwd_ex(_lib.ptr(x), _lib.ptr(wab.reshape(6 * Ci, C)), _lib.ptr(bab), _lib.ptr(A),
                                                 _lib.ptr(PA), _lib.ptr(alpha), _lib.ptr(tp), _lib.ptr(spart), _lib.ptr(P),
-                                                _lib.ptr(adj), _lib.ptr(x_amax_out), ws.data_ptr(), nb, N, C, Ci, T, V,
-                                                _lib.stream()), "agcn_adjacency_fused_fwd")
+                                                _lib.ptr(adj), _lib.ptr(x_amax_out), _lib.ptr(x_amax), ws.data_ptr(), nb, N,
+                                                C, Ci, T, V, _lib.stream()), "agcn_adjacency_fused_fwd")
     return (P, adj, tp) if keep_tp else (P, adj)
 
 
@@ -794,10 +795,10 @@ def gcn_forward(c, x, A, PA, wab, bab, wd, bd, bn, down, training, alpha=None, a
         if x_amax is None and not first and fused_amax_enabled():
             amax_here = _empty((1,), x)    # this pass reads all of x: it takes the maximum along the way
         if keep:
-            P, adj, tp = adjacency_fused_fwd(x, wab, bab, A, PA, alpha, keep_tp=True, x_amax_out=amax_here)
+            P, adj, tp = adjacency_fused_fwd(x, wab, bab, A, PA, alpha, keep_tp=True, x_amax_out=amax_here, x_amax=x_amax)
         else:
             tp = None
-            P, adj = adjacency_fused_fwd(x, wab, bab, A, PA, alpha, x_amax_out=amax_here)
+            P, adj = adjacency_fused_fwd(x, wab, bab, A, PA, alpha, x_amax_out=amax_here, x_amax=x_amax)
         if amax_here is not None:
             x_amax = amax_here
     elif adaptive:

@@ -198,10 +198,13 @@ int agcn_adjacency_fused_fwd(const float* x, const float* wab, const float* bab,
                              const float* alpha, float* tp_out, float* spart, float* P, float* adj, void* workspace,
                              size_t workspace_bytes, int N, int C, int Ci, int T, int V, void* stream);
 /* same; x_absmax_out (optional, 4 bytes) receives max |x| as a by-product of the pass that reads all of x, for the f16x3
- * aggregate+project chain that reads x next (agcn_gcn_aggregate_project_fwd_ex) */
+ * aggregate+project chain that reads x next (agcn_gcn_aggregate_project_fwd_ex); x_absmax_in (optional): max |x| where the
+ * producer of x left it behind (the persistent kernel of the Ci <= 32 layers scales x by it; without it a reduction pass
+ * takes the maximum first) */
 int agcn_adjacency_fused_fwd_ex(const float* x, const float* wab, const float* bab, const float* A, const float* PA,
                                 const float* alpha, float* tp_out, float* spart, float* P, float* adj, float* x_absmax_out,
-                                void* workspace, size_t workspace_bytes, int N, int C, int Ci, int T, int V, void* stream);
+                                const float* x_absmax_in, void* workspace, size_t workspace_bytes, int N, int C, int Ci, int T,
+                                int V, void* stream);
 int agcn_adjacency_fused_bwd_scores(const float* x, const float* wab, const float* bab, const float* dS, float* dtp,
                                     float* dbpart, void* scratch, float* db, void* workspace, size_t workspace_bytes,
                                     int N, int C, int Ci, int T, int V, void* stream);

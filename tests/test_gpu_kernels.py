@@ -278,6 +278,54 @@ def test_adjacency_fused_fwd_bwd(case):
     assert float((db.double().cpu() - db_ref).abs().max()) / max(1e-30, float(db_ref.abs().max())) < 2e-3
 
 
+ADJ_WS_CASES = [(2, 64, 16, 47, 25, 1), (2, 64, 16, 47, 25, 2), (2, 64, 32, 35, 25, 1), (2, 128, 32, 61, 18, 2),
+                (3, 64, 16, 300, 25, 4), (2, 128, 32, 75, 25, 1), (2, 64, 16, 5, 25, 1)]
+
+
+@pytest.mark.parametrize('case', ADJ_WS_CASES)
+def test_adj_ws_multi_tile(case, monkeypatch):
+    """The persistent adjacency forward (csrc/adj_ws.hip) with several tiles per workgroup (the partial scores stay in
+    registers across tiles), ragged last tiles and frame splits; with and without the producer's max |x|; large and
+    tiny activations (the f16x3 range scaling)."""
+    from agcn_amd import ops, lib
+    dev = _gpu()
+    N, C, Ci, T, V, nsplit = case
+    L = ops._L()
+    if L.agcn_gemm_mode().decode() != 'bf16x6' or L.agcn_chain_mode().decode() != 'f16x3':
+        pytest.skip("persistent adjacency kernel runs in the default arithmetic mode only")
+    monkeypatch.setenv('AGCN_AW_SPLIT', str(nsplit))
+    for mag in (1.0, 3e4, 1e-5):
+        g = torch.Generator().manual_seed(11 + C + Ci + T)
+        x = rnd(g, N, C, T, V) * mag
+        wab = rnd(g, 6 * Ci, C, scale=5.0 / np.sqrt(C) * min(1.0 / mag, 16.0))   # (weights stay below 256: F16_W_SCALE)
+        bab = rnd(g, 6 * Ci, scale=0.3)
+        A, PA = rnd(g, 3, V, V, scale=0.2), rnd(g, 3, V, V, scale=0.05)
+        tp = torch.einsum('oc,nctv->notv', wab, x) + bab.view(1, -1, 1, 1)
+        Ps = []
+        for i in range(3):
+            th = tp[:, (2 * i) * Ci:(2 * i + 1) * Ci].permute(0, 3, 1, 2).reshape(N, V, Ci * T)
+            ph = tp[:, (2 * i + 1) * Ci:(2 * i + 2) * Ci].reshape(N, Ci * T, V)
+            Ps.append(torch.softmax(torch.matmul(th, ph) / (Ci * T), dim=-2))
+        P_ref = torch.stack(Ps, 1)
+        xg, wg, bg = x.float().to(dev), wab.float().to(dev), bab.float().to(dev)
+        Ag, PAg = A.float().to(dev), PA.float().to(dev)
+        P, adj, tpk = ops.adjacency_fused_fwd(xg, wg, bg, Ag, PAg, keep_tp=True)
+        assert L.agcn_last_kernel().decode().startswith('adj_ws_kernel'), L.agcn_last_kernel()
+        assert rel(P, P_ref) < TOL, (mag, rel(P, P_ref))
+        assert rel(adj, P_ref + A + PA) < TOL
+        assert rel(tpk, tp) < TOL
+        amax = xg.abs().max().reshape(1)
+        out = torch.empty(1, device=dev)
+        P2, adj2 = ops.adjacency_fused_fwd(xg, wg, bg, Ag, PAg, x_amax=amax, x_amax_out=out)
+        assert torch.equal(P2, P) and torch.equal(adj2, adj) and torch.equal(out, amax)
+        out.zero_()
+        P3, _ = ops.adjacency_fused_fwd(xg, wg, bg, Ag, PAg, x_amax_out=out)
+        assert torch.equal(P3, P) and torch.equal(out, amax)
+        for _ in range(5):                                      # bit-for-bit on repeats
+            P4, adj4, tp4 = ops.adjacency_fused_fwd(xg, wg, bg, Ag, PAg, keep_tp=True, x_amax=amax)
+            assert torch.equal(P4, P) and torch.equal(adj4, adj) and torch.equal(tp4, tpk)
+
+
 BN_CASES = [(2, 64, 23, 25, 0), (2, 64, 23, 25, 1), (3, 128, 11, 25, 2), (2, 256, 7, 25, 2), (2, 64, 17, 18, 1)]
 
 

@@ -41,3 +41,19 @@ for name, sa, sb in [('activations ~ N(0,1) x weights ~ N(0,1)/sqrt(K)', 1.0, K 
         rows.append('%s %.1e' % (label, err))
     f32 = ((a @ b).double() - ref).abs().max() / scale
     print('%-55s fp32 GEMM %.1e | %s' % (name, f32.item(), ' | '.join(rows)))
+
+# Small weights (the reference's conv_d initialisation: std sqrt(2 / (Cout * C * 3)) = 0.0128 at 64 channels, 0.0032 at 256):
+# the residual plane of an unscaled weight is an fp16 subnormal; F16_W_SCALE = 2^8 (csrc/split_f16.h) restores it.
+print()
+K2 = 768
+for std in (0.3, 0.0128, 0.0032, 0.001):
+    a = torch.randn(M, K2) * 2.0 ** 12          # activations after their range scale
+    b = torch.randn(K2, N) * std
+    ref = a.double() @ b.double()
+    scale = ref.abs().max()
+    f32 = (((a @ b).double() - ref).abs().max() / scale).item()
+    row = []
+    for ws in (1.0, 256.0):
+        r = gemm(a, b * ws, torch.float16, 2, P3) / ws
+        row.append('weights x %-3g f16x3 %.1e' % (ws, ((r - ref).abs().max() / scale).item()))
+    print('weights ~ N(0, %-6g)  fp32 GEMM %.1e | %s' % (std, f32, ' | '.join(row)))
