@@ -388,6 +388,106 @@ scores_bwd_kernel(const float* __restrict__ tp, const float* __restrict__ dS, fl
   }
 }
 
+// The same gradient, one WAVE per (sample, subset, theta|phi, channel) row block and no LDS at all.  A row block is T
+// contiguous rows of V floats, both in tp and in dtp, and the exact-f32 matrix op wants exactly that shape:
+//   dtheta[t, u] = sum_v phi[t, v] dS[u, v]      A = 32 frames x V (lane (t, h) reads element 2s + h of its row: two cache
+//   dphi[t, v]   = sum_u theta[t, u] dS[u, v]    lines' worth of one 32-row run per instruction), B = dS (or its transpose),
+// held in VS registers per lane for the wave's life; D = 32 frames x V joints leaves as 16 stores of two 4V-byte row pieces.
+// The next tile's A operands are in flight while this tile's VS matrix ops run.  Nothing is staged, nothing waits on a
+// barrier; the conv_a/conv_b bias gradient of the row block is one wave reduction at the end (one slot per sample).
+template <int V, int VS>
+__global__ void __launch_bounds__(256) scores_bwd_rows_kernel(const float* __restrict__ tp, const float* __restrict__ dS,
+                                                              float* __restrict__ dtp, float* __restrict__ dbpart,
+                                                              unsigned* __restrict__ amax, int N, int Ci, int T) {
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int lr = lane & 31, h = lane >> 5;
+  const int unit = blockIdx.x * 4 + wave;              // ((n * 3 + i) * 2 + which) * Ci + c
+  if (unit >= N * 6 * Ci) return;                      // (wave-uniform; no barriers in this kernel)
+  const int c = unit % Ci, which = (unit / Ci) & 1, ni = unit / (2 * Ci);
+  const int n = ni / 3, i = ni - 3 * n;
+  const long P = (long)T * V;
+  const long row_th = (long)n * 6 * Ci + (long)i * 2 * Ci + c, row_ph = row_th + Ci;
+  const float* src = tp + (which == 0 ? row_ph : row_th) * P;
+  float* dst = dtp + (which == 0 ? row_th : row_ph) * P;
+  const float* dsn = dS + (long)ni * V * V;
+  float bq[VS];
+#pragma unroll
+  for (int s = 0; s < VS; ++s) {
+    const int k = 2 * s + h;
+    const bool ok = k < V && lr < V;
+    const float v = dsn[ok ? (which == 0 ? lr * V + k : k * V + lr) : 0];
+    bq[s] = ok ? v : 0.f;
+  }
+  const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(src), 0, (int)(P * 4), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rd = __builtin_amdgcn_make_buffer_rsrc(dst, 0, (int)(P * 4), 0x00020000);
+  auto load_a = [&](int t0, float (&av)[VS]) __attribute__((always_inline)) {
+    const int vo = (min(t0 + lr, T - 1) * V + h) * 4;
+#pragma unroll
+    for (int s = 0; s < VS; ++s)                       // (element V of a row is the next row's first: masked below; past the
+      av[s] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, vo + 8 * s, 0, 0));   // block: reads 0)
+  };
+  float av[2][VS];
+  load_a(0, av[0]);
+  float bsum = 0.f;
+  unsigned mx = 0;
+  const int ntile = (T + 31) >> 5;
+#pragma unroll 1
+  for (int tb = 0; tb < ntile; tb += 2) {
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      const int t0 = (tb + q) * 32;
+      if (t0 < T) {                                    // (wave-uniform)
+        if (t0 + 32 < T) load_a(t0 + 32, av[q ^ 1]);
+        f32x16 d;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) d[j] = 0.f;
+#pragma unroll
+        for (int s = 0; s < VS; ++s) {
+          const float a = (2 * s + 1 < V || h == 0) ? av[q][s] : 0.f;
+          d = mfma32(a, bq[s], d);
+        }
+        if (lr < V) {
+          const int vo = ((t0 + 4 * h) * V + lr) * 4;  // rows past T fall outside the descriptor: dropped
+#pragma unroll
+          for (int j = 0; j < 16; ++j) {
+            const int rj = (j & 3) + 8 * (j >> 2);
+            const float dj = d[j];                     // (through a float: __builtin_bit_cast on a vector ELEMENT reads element 0)
+            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, dj), rd, vo + rj * V * 4, 0, 0);
+            const bool ok = t0 + 4 * h + rj < T;
+            const float z = ok ? dj : 0.f;
+            bsum += z;
+            mx = max(mx, __float_as_uint(z) & 0x7fffffffu);
+          }
+        }
+      }
+    }
+  }
+  bsum = half_sum(bsum);
+  bsum += __shfl_xor(bsum, 32);
+  if (lane == 0) dbpart[which == 0 ? row_th : row_ph] = bsum;       // (N, 6 Ci)
+  if (amax) {
+#pragma unroll
+    for (int k = 32; k >= 1; k >>= 1) mx = max(mx, (unsigned)__shfl_xor((int)mx, k));
+    if (lane == 0 && mx > __hip_atomic_load(amax, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(amax, mx);
+  }
+}
+
+template <int V, int VS>
+int scores_bwd_rows_launch(const float* tp, const float* dS, float* dtp, float* dbpart, unsigned* amax, int N, int Ci, int T,
+                           hipStream_t s) {
+  const int units = N * 6 * Ci;
+  hipLaunchKernelGGL((scores_bwd_rows_kernel<V, VS>), dim3((units + 3) / 4), dim3(256), 0, s, tp, dS, dtp, dbpart, amax, N, Ci,
+                     T);
+  AGCN_NOTE_KERNEL("scores_bwd_rows_kernel<%d, %d>", V, VS);
+  return agcn_check_launch();
+}
+// AGCN_SCORES_ROWS=0 keeps the LDS-staged kernel (A/B)
+static inline bool scores_rows_enabled() {
+  static const int on = getenv("AGCN_SCORES_ROWS") ? atoi(getenv("AGCN_SCORES_ROWS")) : 1;
+  return on != 0;
+}
+
 inline int sc_tile_frames(int V, int T) {
   int tt = 256 / V;
   return tt > T ? T : tt;
@@ -460,6 +560,13 @@ int agcn_adjacency_bwd_scores_ex(const float* tp, const float* dS, float* dtp, f
   const int VP = 2 * ((V + 1) / 2);
   const size_t smem = 4 * ((size_t)2 * SC_CK * tt * V + 2 * VP * 32 + 2 * SC_CK * tt);
   if (dtp_absmax_out && hipMemsetAsync(dtp_absmax_out, 0, 4, s) != hipSuccess) return AGCN_ERR_ARG;
+  if (scores_rows_enabled() && (V == 25 || V == 18) && (long)T * V * 4 < (1L << 31)) {
+    unsigned* am = reinterpret_cast<unsigned*>(dtp_absmax_out);
+    int rc = V == 25 ? scores_bwd_rows_launch<25, 13>(tp, dS, dtp, dbpart, am, N, Ci, T, s)
+                     : scores_bwd_rows_launch<18, 9>(tp, dS, dtp, dbpart, am, N, Ci, T, s);
+    if (rc) return rc;
+    return agcn_colsum(dbpart, N, 6 * Ci, scratch, db, stream);      // one slot of row sums per sample
+  }
   hipLaunchKernelGGL(scores_bwd_kernel, dim3(N * ntiles, 3), dim3(256), smem, s, tp, dS, dtp, dbpart,
                      reinterpret_cast<unsigned*>(dtp_absmax_out), N, Ci, T, V, tt, ntiles);
   int rc = agcn_check_launch();

@@ -109,7 +109,7 @@ int agcn_wgrad_chain(int agg, const float* dy, const float* x, const float* adj,
 bool agcn_wgrad9_bf16_supported(int M, int C, int V, int stride);
 size_t agcn_wgrad9_bf16_workspace(int N, int M, int C, int V, int T, int stride);
 int agcn_wgrad9_bf16(const float* dy, const float* x, void* ws, size_t ws_bytes, int* nslabs, int N, int M, int C, int V,
-                     int T, int stride, hipStream_t s);
+                     int T, int stride, hipStream_t s, const float* dy_absmax = nullptr, const float* x_absmax = nullptr);
 
 // GEMM arithmetic of the channel contractions: 3 = bf16x6 (default: fp32-equivalent accuracy, measured), 0 = f32 MFMA,
 // 2 = bf16x3 (~5e-6 per GEMM; does NOT hold the 1e-4 parity bar end to end), 1 = bf16 (plain bf16 MFMA operands, ONE

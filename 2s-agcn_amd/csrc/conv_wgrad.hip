@@ -448,7 +448,7 @@ int agcn_conv_bwd_weight_ex(const float* dy, const float* x, float* dw, void* wo
   if (taps == 9) {
     if (wgrad9_bf16_enabled() && agcn_wgrad9_bf16_supported(Cout, Cin, V, stride)) {
       int nslabs = 0;
-      int rc = agcn_wgrad9_bf16(dy, x, workspace, workspace_bytes, &nslabs, N, Cout, Cin, V, T, stride, s);
+      int rc = agcn_wgrad9_bf16(dy, x, workspace, workspace_bytes, &nslabs, N, Cout, Cin, V, T, stride, s, dy_absmax, x_absmax);
       if (rc) return rc;
       return launch_reduce((const float*)workspace, dw, a.wsize, nslabs, a.M, a.C, a.so_m, a.so_t, a.so_c, s);
     }

@@ -19,6 +19,7 @@
 // fixed order by the caller's slab reduction (bitwise reproducible).
 #include "agcn_common.h"
 #include "split_bf16.h"
+#include "split_f16.h"
 
 namespace {
 
@@ -31,14 +32,22 @@ struct TrArgs {
   const float* in;   // (N, R, T, V)
   float* out;        // (N, V, R, S, Tp): frame t goes to parity row t % S, position t / S  (S = 1: plain t-contiguous rows)
   int N, R, T, V, Tp, S;
+  const float* absmax;   // F16: device scalar max |in| (range scale); the output is two fp16 planes of `plane` elements each
+  long plane;
 };
 
 // (N, R, T, V) -> (N, V, R, Tp): t-contiguous rows, [T, Tp) zero.  A workgroup moves 8 rows x 64 frames through LDS:
 // the source tile (8 contiguous runs of 64*V floats) comes in by direct-to-LDS loads (no registers, every load of the
 // tile in flight at once: ~50 KB per workgroup, three workgroups per CU), and leaves as 16-byte stores of 4 frames.
+// F16: the copy is written as the two fp16 planes of the f16x3 split (hi, then residual; same bytes as the fp32 copy),
+// range-scaled by max |in|: the main kernel then loads matrix operands as they are, with no conversion work left in it.
+// The F16 variant moves RB = 4 rows x TT = 128 frames per workgroup and a lane writes FPL = 8 frames: 16-byte stores, 256
+// contiguous bytes per (joint, row, plane) instead of 128.
+template <bool F16, int RB, int TT, int FPL>
 __global__ void __launch_bounds__(256) tv_transpose_kernel(const TrArgs a) {
   extern __shared__ __attribute__((aligned(16))) float tile[];
-  constexpr int RB = 8, TT = 64;
+  static_assert(FPL == 4 || (F16 && FPL == 8), "a lane writes one 16-byte store per plane");
+  constexpr int QL = TT / FPL, NSUB = 64 / QL;   // lanes per (joint, row) pair, pairs per wave-instruction
   const int S = a.S;
   const int ntt = (a.Tp * S + TT - 1) / TT, nrb = (a.R + RB - 1) / RB;
   int b = blockIdx.x;
@@ -63,20 +72,39 @@ __global__ void __launch_bounds__(256) tv_transpose_kernel(const TrArgs a) {
     }
   }
   __syncthreads();                               // (drains the LDS-DMA: the compiler waits vmcnt(0) here)
+  float rs_s = 1.f, rs_inv = 1.f;
+  if constexpr (F16) f16_range_scale(a.absmax, rs_s, rs_inv);
+  (void)rs_inv;
   const int TTo = TT / S;                        // output positions per parity row in this tile
-  const int tw = min(TTo, a.Tp - t0 / S);        // positions written per parity row (zero pad included); multiple of 4
-  const int qp = TTo / 4;                        // quads per parity row: 16 (S = 1) or 8 (S = 2)
-  const int par = (lane & 15) / qp, q = (lane & 15) - par * qp, sub = lane >> 4;
-  for (int p = wave * 4 + sub; p < a.V * RB; p += 16) {      // lane -> (parity, quad), 4 (joint, row) pairs per instruction
+  const int tw = min(TTo, a.Tp - t0 / S);        // positions written per parity row (zero pad included); multiple of FPL
+  const int qp = TTo / FPL;                      // lanes per parity row
+  const int lq = lane % QL;
+  const int par = lq / qp, q = lq - par * qp, sub = lane / QL;
+  for (int p = wave * NSUB + sub; p < a.V * RB; p += 4 * NSUB) {   // lane -> (parity, group), NSUB (joint, row) pairs per instruction
     const int v = p / RB, r = p - v * RB;
-    if (r0 + r < a.R && 4 * q < tw) {
-      f32x4 val;
+    if (r0 + r < a.R && FPL * q < tw) {
+      float val[FPL];
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const int f = (4 * q + j) * S + par;     // source frame within the tile
+      for (int j = 0; j < FPL; ++j) {
+        const int f = (FPL * q + j) * S + par;   // source frame within the tile
         val[j] = (f < tl) ? tile[r * pitch + f * a.V + v] : 0.f;
       }
-      *reinterpret_cast<f32x4*>(a.out + ((((long)n * a.V + v) * a.R + r0 + r) * S + par) * a.Tp + t0 / S + 4 * q) = val;
+      const long o = ((((long)n * a.V + v) * a.R + r0 + r) * S + par) * a.Tp + t0 / S + FPL * q;
+      if constexpr (F16) {
+        unsigned hh[FPL / 2], ll[FPL / 2];
+#pragma unroll
+        for (int j = 0; j < FPL / 2; ++j) split_pair_f16_mix(val[2 * j] * rs_s, val[2 * j + 1] * rs_s, hh[j], ll[j]);
+        unsigned short* oh = reinterpret_cast<unsigned short*>(a.out);
+        if constexpr (FPL == 8) {
+          *reinterpret_cast<u32x4*>(oh + o) = u32x4{hh[0], hh[1], hh[2], hh[3]};
+          *reinterpret_cast<u32x4*>(oh + a.plane + o) = u32x4{ll[0], ll[1], ll[2], ll[3]};
+        } else {
+          *reinterpret_cast<uint2*>(oh + o) = make_uint2(hh[0], hh[1]);
+          *reinterpret_cast<uint2*>(oh + a.plane + o) = make_uint2(ll[0], ll[1]);
+        }
+      } else {
+        *reinterpret_cast<f32x4*>(a.out + o) = f32x4{val[0], val[1], val[2], val[3]};
+      }
     }
   }
 }
@@ -88,6 +116,12 @@ struct W9Args {
   int N, M, C, V, T, Tp;
   int nchunk, units, units_per_split, ncb;
   int npl;            // 3: six split products (bf16x6) ; 1: hi*hi only (bf16)
+  // f16x3 variant: the transposed copies are fp16 plane pairs (plane stride in elements), scaled by these maxima
+  const unsigned short* dyH;
+  const unsigned short* xH;
+  long dy_plane, x_plane;
+  const float* dy_absmax;
+  const float* x_absmax;
 };
 
 // elements s .. s+7 of a 16-element window held as 8 packed bf16 pairs
@@ -268,16 +302,187 @@ __global__ void __launch_bounds__(256, 2) wgrad9_bf16_kernel(const W9Args a) {
     }
 }
 
+
+// f16x3 variant (split_f16.h): the operands arrive as fp16 plane pairs from the transposer, so a unit is staged with plain
+// 8-byte copies and a K-step is 6 wide LDS reads + 27 MFMAs (9 taps x 3 products) + the odd taps' v_alignbit: half the
+// matrix work of bf16x6 and none of its conversion work.
+constexpr int DPH = 88;       // LDS pitch of a dy row of one fp16 plane (elements): 176 bytes = 16 * odd
+
+template <int S>
+__device__ __forceinline__ f32x16 tap_mfma_f16(f16x8 ah, f16x8 al, const unsigned (&ph)[8], const unsigned (&pl)[8],
+                                               f32x16 c) {
+  const f16x8 bh = __builtin_bit_cast(f16x8, window_frag<S>(ph)), bl = __builtin_bit_cast(f16x8, window_frag<S>(pl));
+  c = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, c, 0, 0, 0);
+  c = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, c, 0, 0, 0);
+  c = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, c, 0, 0, 0);
+  return c;
+}
+
+template <int RT, int CT, int STRIDE>
+__global__ void __launch_bounds__(256, 2) wgrad9_f16_kernel(const W9Args a) {
+  constexpr int NT = 256, BM = RT * 32, CBW = CT * 32, SETS = STRIDE;
+  static_assert(RT * CT == 4, "four waves");
+  constexpr int ND = BM * (TC / 4) / NT;                 // 4-frame groups of the dy tile per thread and plane (exact)
+  constexpr int NXG = CBW * SETS * (XW / 8);             // 8-frame groups of the x tile (parity rows count as rows)
+  constexpr int NX = (NXG + NT - 1) / NT;
+  static_assert(BM * (TC / 4) % NT == 0, "dy tile divides evenly");
+  extern __shared__ __attribute__((aligned(16))) unsigned short smh[];
+  unsigned short* dyL = smh;                             // [2 planes][BM][DPH]
+  unsigned short* xP = smh + 2 * BM * DPH;               // [2 planes][SETS][CBW][XPB]
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int lr = lane & 31, h = lane >> 5;
+  const int rt = wave % RT, ct = wave / RT;
+  const int mb = blockIdx.x / a.ncb, cb = blockIdx.x - mb * a.ncb;
+  const int m0 = mb * BM, c0 = cb * CBW;
+  const int split = blockIdx.y;
+  const int u_begin = split * a.units_per_split;
+  const int u_end = min(a.units, u_begin + a.units_per_split);
+  const int Tp = a.Tp;
+
+  f32x16 acc[9];
+#pragma unroll
+  for (int z = 0; z < 9; ++z)
+#pragma unroll
+    for (int j = 0; j < 16; ++j) acc[z][j] = 0.f;
+
+  const unsigned short* arow = dyL + (rt * 32 + lr) * DPH + 8 * h;            // + plane * BM * DPH
+  const unsigned short* brow = xP + (ct * 32 + lr) * XPB + 8 * h;             // + (plane * SETS + set) * CBW * XPB
+
+  // A unit's operands are fetched into registers ONE UNIT AHEAD (PREF; all loads in flight at once, nothing consumes them
+  // until the next unit's staging), so that their latency runs under this unit's 135 matrix operations; the stride-2
+  // variant has no registers left for that and relies on the CU's other workgroup instead.
+  constexpr bool PREF = STRIDE == 1;
+  uint2 dv[ND][2], xv[NX][2][2];
+  auto fetch = [&](int unit) __attribute__((always_inline)) {
+    const int ch = unit % a.nchunk;
+    const int nv = unit / a.nchunk;              // n * V + v
+    const int t0 = ch * TC;
+    const unsigned short* src = a.dyH + ((long)nv * a.M + m0) * Tp + t0;
+    const unsigned short* sx = a.xH + ((long)nv * a.C + c0) * SETS * Tp + (t0 - 4);   // rows: (channel, parity)
+    int tv = tid;                                // (laundered: see the bf16 kernel)
+    asm volatile("" : "+v"(tv));
+#pragma unroll
+    for (int u = 0; u < ND; ++u) {
+      const int i = tv + u * NT, r = i / (TC / 4), q = i - r * (TC / 4);
+      const bool ok = (m0 + r < a.M) && (t0 + 4 * q < Tp);
+      const int off = ok ? r * Tp + 4 * q : 0;
+#pragma unroll
+      for (int pl = 0; pl < 2; ++pl) {
+        dv[u][pl] = *reinterpret_cast<const uint2*>(src + pl * a.dy_plane + off);
+        if (!ok) dv[u][pl] = make_uint2(0u, 0u);
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < NX; ++u) {
+      const int i = min(tv + u * NT, NXG - 1), r = i / (XW / 8), k = i - r * (XW / 8);      // r = channel * SETS + parity
+#pragma unroll
+      for (int hq = 0; hq < 2; ++hq) {
+        const int t = t0 - 4 + 8 * k + 4 * hq;
+        const bool ok = (c0 + r / SETS < a.C) && t >= 0 && t < Tp;
+        const int off = ok ? r * Tp + 8 * k + 4 * hq : 4;
+#pragma unroll
+        for (int pl = 0; pl < 2; ++pl) {
+          xv[u][hq][pl] = *reinterpret_cast<const uint2*>(sx + pl * a.x_plane + off);
+          if (!ok) xv[u][hq][pl] = make_uint2(0u, 0u);
+        }
+      }
+    }
+  };
+  if (PREF && u_begin < u_end) fetch(u_begin);
+  for (int unit = u_begin; unit < u_end; ++unit) {
+    if (!PREF) fetch(unit);
+    __syncthreads();                             // the previous unit's fragment reads are done
+    int tv = tid;
+    asm volatile("" : "+v"(tv));
+#pragma unroll
+    for (int u = 0; u < ND; ++u) {
+      const int i = tv + u * NT, r = i / (TC / 4), q = i - r * (TC / 4);
+#pragma unroll
+      for (int pl = 0; pl < 2; ++pl) *reinterpret_cast<uint2*>(dyL + (pl * BM + r) * DPH + 4 * q) = dv[u][pl];
+    }
+#pragma unroll
+    for (int u = 0; u < NX; ++u) {               // (tail threads rewrite the last group with its own value)
+      const int i = min(tv + u * NT, NXG - 1), r = i / (XW / 8), k = i - r * (XW / 8);
+      const int row = (r % SETS) * CBW + r / SETS;           // LDS rows: [plane][parity][channel]
+#pragma unroll
+      for (int hq = 0; hq < 2; ++hq)
+#pragma unroll
+        for (int pl = 0; pl < 2; ++pl)
+          *reinterpret_cast<uint2*>(xP + (pl * SETS * CBW + row) * XPB + 8 * k + 4 * hq) = xv[u][hq][pl];
+    }
+    __syncthreads();
+    if (PREF && unit + 1 < u_end) fetch(unit + 1);
+#pragma unroll 1
+    for (int ks = 0; ks < TC / 16; ++ks) {
+      // A fragment: 8 consecutive frames of this lane's dy row ; B window: 16 consecutive frames of its x row
+      const f16x8 ah = *reinterpret_cast<const f16x8*>(arow + 16 * ks);
+      const f16x8 al = *reinterpret_cast<const f16x8*>(arow + BM * DPH + 16 * ks);
+      u32x4 bw[SETS][2][2];                        // 16-frame window of each plane (of each parity row)
+#pragma unroll
+      for (int st = 0; st < SETS; ++st)
+#pragma unroll
+        for (int pl = 0; pl < 2; ++pl)
+#pragma unroll
+          for (int i = 0; i < 2; ++i)
+            bw[st][pl][i] = *reinterpret_cast<const u32x4*>(brow + (pl * SETS + st) * CBW * XPB + 16 * ks + 8 * i);
+      unsigned p0[8], p1[8], o0[8], o1[8];         // even-row (or only) window, odd-row window
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        p0[i] = bw[0][0][i >> 2][i & 3];
+        p1[i] = bw[0][1][i >> 2][i & 3];
+        o0[i] = bw[SETS - 1][0][i >> 2][i & 3];
+        o1[i] = bw[SETS - 1][1][i >> 2][i & 3];
+      }
+      if (STRIDE == 1) {                           // tap k = window shift k
+        acc[0] = tap_mfma_f16<0>(ah, al, p0, p1, acc[0]);
+        acc[1] = tap_mfma_f16<1>(ah, al, p0, p1, acc[1]);
+        acc[2] = tap_mfma_f16<2>(ah, al, p0, p1, acc[2]);
+        acc[3] = tap_mfma_f16<3>(ah, al, p0, p1, acc[3]);
+        acc[4] = tap_mfma_f16<4>(ah, al, p0, p1, acc[4]);
+        acc[5] = tap_mfma_f16<5>(ah, al, p0, p1, acc[5]);
+        acc[6] = tap_mfma_f16<6>(ah, al, p0, p1, acc[6]);
+        acc[7] = tap_mfma_f16<7>(ah, al, p0, p1, acc[7]);
+        acc[8] = tap_mfma_f16<8>(ah, al, p0, p1, acc[8]);
+      } else {                                     // even taps: xE shifted by 4 + (k-4)/2 ; odd taps: xO by 4 + (k-5)/2
+        acc[0] = tap_mfma_f16<2>(ah, al, p0, p1, acc[0]);
+        acc[1] = tap_mfma_f16<2>(ah, al, o0, o1, acc[1]);
+        acc[2] = tap_mfma_f16<3>(ah, al, p0, p1, acc[2]);
+        acc[3] = tap_mfma_f16<3>(ah, al, o0, o1, acc[3]);
+        acc[4] = tap_mfma_f16<4>(ah, al, p0, p1, acc[4]);
+        acc[5] = tap_mfma_f16<4>(ah, al, o0, o1, acc[5]);
+        acc[6] = tap_mfma_f16<5>(ah, al, p0, p1, acc[6]);
+        acc[7] = tap_mfma_f16<5>(ah, al, o0, o1, acc[7]);
+        acc[8] = tap_mfma_f16<6>(ah, al, p0, p1, acc[8]);
+      }
+    }
+  }
+
+  float s_dy, inv_dy, s_x, inv_x;
+  f16_range_scale(a.dy_absmax, s_dy, inv_dy);
+  f16_range_scale(a.x_absmax, s_x, inv_x);
+  const float inv = inv_dy * inv_x;
+  float* dst = a.part + (long)split * 9 * a.M * a.C;
+#pragma unroll
+  for (int z = 0; z < 9; ++z)
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+      const int m = m0 + rt * 32 + mfma_row(j, h);
+      const int c = c0 + ct * 32 + lr;
+      if (m < a.M && c < a.C) dst[((long)z * a.M + m) * a.C + c] = acc[z][j] * inv;
+    }
+}
+
 struct W9Geom {
   int Tp, nchunk, units, nmb, ncb, nsplit, units_per_split, rt;
-  size_t slab_bytes, dyT_bytes, xT_bytes, smem_bytes;
+  size_t slab_bytes, dyT_bytes, xT_bytes, smem_bytes, smem_f16;
 };
 
 inline W9Geom w9_geometry(int N, int M, int C, int V, int T, int stride) {      // T = OUTPUT frames
   W9Geom g;
   g.rt = (M % 128 == 0) ? 4 : 2;
   const int BM = g.rt * 32, CBW = (4 / g.rt) * 32;
-  g.Tp = (T + 3) & ~3;
+  g.Tp = (T + 7) & ~7;                               // (the fp16 transposer writes 8 frames per lane)
   g.nchunk = (T + TC - 1) / TC;
   g.units = N * V * g.nchunk;
   g.nmb = (M + BM - 1) / BM;
@@ -292,15 +497,44 @@ inline W9Geom w9_geometry(int N, int M, int C, int V, int T, int stride) {      
   g.dyT_bytes = (size_t)N * V * M * g.Tp * 4;
   g.xT_bytes = (size_t)N * V * C * stride * g.Tp * 4;
   g.smem_bytes = (size_t)BM * DP * 4 + (size_t)3 * stride * CBW * XPB * 2;
+  g.smem_f16 = (size_t)2 * BM * DPH * 2 + (size_t)2 * stride * CBW * XPB * 2;
   return g;
 }
 
-int w9_transpose(const float* in, float* out, int N, int R, int T, int V, int Tp, int S, hipStream_t s) {
+int w9_transpose(const float* in, float* out, int N, int R, int T, int V, int Tp, int S, hipStream_t s,
+                 const float* absmax = nullptr) {
   TrArgs t;
   t.in = in; t.out = out; t.N = N; t.R = R; t.T = T; t.V = V; t.Tp = Tp; t.S = S;
-  const int ntt = (Tp * S + 63) / 64, nrb = (R + 7) / 8;
-  const size_t smem = (size_t)8 * (64 * V + 4) * 4;
-  hipLaunchKernelGGL(tv_transpose_kernel, dim3((unsigned)(N * nrb * ntt)), dim3(256), smem, s, t);
+  t.absmax = absmax; t.plane = (long)N * V * R * S * Tp;
+  if (absmax) {                                  // fp16 plane pairs (Tp is a multiple of 8)
+    // 128-frame tiles where the source frames fill them (measured: T = 75 and 300 gain, T = 150 = 128 + 22 loses)
+    const int rem = T % 128;
+    if (T <= 128 || rem == 0 || rem > 64) {
+      constexpr int RB = 4, TT = 128;
+      const int ntt = (Tp * S + TT - 1) / TT, nrb = (R + RB - 1) / RB;
+      const size_t smem = (size_t)RB * (TT * V + 4) * 4;
+      hipLaunchKernelGGL((tv_transpose_kernel<true, RB, TT, 8>), dim3((unsigned)(N * nrb * ntt)), dim3(256), smem, s, t);
+    } else {
+      constexpr int RB = 8, TT = 64;
+      const int ntt = (Tp * S + TT - 1) / TT, nrb = (R + RB - 1) / RB;
+      const size_t smem = (size_t)RB * (TT * V + 4) * 4;
+      hipLaunchKernelGGL((tv_transpose_kernel<true, RB, TT, 8>), dim3((unsigned)(N * nrb * ntt)), dim3(256), smem, s, t);
+    }
+  } else {
+    const int ntt = (Tp * S + 63) / 64, nrb = (R + 7) / 8;
+    const size_t smem = (size_t)8 * (64 * V + 4) * 4;
+    hipLaunchKernelGGL((tv_transpose_kernel<false, 8, 64, 4>), dim3((unsigned)(N * nrb * ntt)), dim3(256), smem, s, t);
+  }
+  return agcn_check_launch();
+}
+
+template <int RT, int CT, int STRIDE>
+int w9_launch_f16(const W9Args& a, const W9Geom& g, hipStream_t s) {
+  constexpr auto kern = wgrad9_f16_kernel<RT, CT, STRIDE>;
+  int rc = agcn_allow_big_lds<kern>();
+  if (rc) return rc;
+  AGCN_NOTE_KERNEL("wgrad9_f16_kernel<%d, %d, %d>", RT, CT, STRIDE);
+  hipLaunchKernelGGL(kern, dim3((unsigned)(g.nmb * g.ncb), (unsigned)g.nsplit), dim3(256), g.smem_f16, s, a);
   return agcn_check_launch();
 }
 
@@ -326,29 +560,58 @@ bool agcn_wgrad9_bf16_supported(int M, int C, int V, int stride) {
 // T = frames of x; the convolution output has (T - 1) / stride + 1 frames
 size_t agcn_wgrad9_bf16_workspace(int N, int M, int C, int V, int T, int stride) {
   const W9Geom g = w9_geometry(N, M, C, V, (T - 1) / stride + 1, stride);
-  return g.slab_bytes + g.dyT_bytes + g.xT_bytes + 256;
+  return g.slab_bytes + g.dyT_bytes + g.xT_bytes + 512;      // (alignment of the copies + two scalars behind them)
 }
 
-// writes *nslabs slabs [9][M][C] at the start of ws (to be summed by the caller's slab reduction)
+// AGCN_WGRAD9_F16X3=0 keeps the 9-tap weight gradient on bf16x6 (A/B)
+static inline bool w9_f16x3() {
+  static const int on = getenv("AGCN_WGRAD9_F16X3") ? atoi(getenv("AGCN_WGRAD9_F16X3")) : 1;
+  return on != 0;
+}
+
+// writes *nslabs slabs [9][M][C] at the start of ws (to be summed by the caller's slab reduction).
+// dy_absmax / x_absmax: device scalars max |dy| / max |x| where their producers left them behind (f16x3 range scales; a
+// reduction pass takes a missing one).
 int agcn_wgrad9_bf16(const float* dy, const float* x, void* ws, size_t ws_bytes, int* nslabs, int N, int M, int C, int V,
-                     int T, int stride, hipStream_t s) {
+                     int T, int stride, hipStream_t s, const float* dy_absmax, const float* x_absmax) {
   const int To = (T - 1) / stride + 1;
   const W9Geom g = w9_geometry(N, M, C, V, To, stride);
-  if (g.slab_bytes + g.dyT_bytes + g.xT_bytes > ws_bytes) return AGCN_ERR_WORKSPACE;
+  if (g.slab_bytes + g.dyT_bytes + g.xT_bytes + 512 > ws_bytes) return AGCN_ERR_WORKSPACE;
   unsigned char* base = (unsigned char*)ws;
   float* dyT = (float*)(base + ((g.slab_bytes + 255) & ~(size_t)255));
   float* xT = (float*)((unsigned char*)dyT + g.dyT_bytes);
-  if ((size_t)((unsigned char*)xT - base) + g.xT_bytes > ws_bytes) return AGCN_ERR_WORKSPACE;
-  int rc = w9_transpose(dy, dyT, N, M, To, V, g.Tp, 1, s);
+  if ((size_t)((unsigned char*)xT - base) + g.xT_bytes + 8 > ws_bytes) return AGCN_ERR_WORKSPACE;
+  const bool f16 = agcn_npl() == 3 && w9_f16x3();
+  if (f16) {
+    unsigned* scr = reinterpret_cast<unsigned*>((unsigned char*)xT + g.xT_bytes);     // two scalars behind the copies
+    if (!dy_absmax) {
+      if (int rc = agcn_launch_absmax(dy, (long)N * M * To * V, scr, s)) return rc;
+      dy_absmax = reinterpret_cast<const float*>(scr);
+    }
+    if (!x_absmax) {
+      if (int rc = agcn_launch_absmax(x, (long)N * C * T * V, scr + 1, s)) return rc;
+      x_absmax = reinterpret_cast<const float*>(scr + 1);
+    }
+  }
+  int rc = w9_transpose(dy, dyT, N, M, To, V, g.Tp, 1, s, f16 ? dy_absmax : nullptr);
   if (rc) return rc;
-  rc = w9_transpose(x, xT, N, C, T, V, g.Tp, stride, s);
+  rc = w9_transpose(x, xT, N, C, T, V, g.Tp, stride, s, f16 ? x_absmax : nullptr);
   if (rc) return rc;
-  W9Args a;
+  W9Args a = {};
   a.dyT = dyT; a.xT = xT; a.part = (float*)ws;
   a.N = N; a.M = M; a.C = C; a.V = V; a.T = To; a.Tp = g.Tp;
   a.nchunk = g.nchunk; a.units = g.units; a.units_per_split = g.units_per_split; a.ncb = g.ncb;
   a.npl = agcn_npl();
   *nslabs = g.nsplit;
+  if (f16) {
+    a.dyH = reinterpret_cast<const unsigned short*>(dyT);
+    a.xH = reinterpret_cast<const unsigned short*>(xT);
+    a.dy_plane = (long)N * V * M * g.Tp;
+    a.x_plane = (long)N * V * C * stride * g.Tp;
+    a.dy_absmax = dy_absmax; a.x_absmax = x_absmax;
+    if (stride == 2) return w9_launch_f16<4, 1, 2>(a, g, s);
+    return g.rt == 4 ? w9_launch_f16<4, 1, 1>(a, g, s) : w9_launch_f16<2, 2, 1>(a, g, s);
+  }
   if (stride == 2) return w9_launch<4, 1, 2>(a, g, s);
   return g.rt == 4 ? w9_launch<4, 1, 1>(a, g, s) : w9_launch<2, 2, 1>(a, g, s);
 }

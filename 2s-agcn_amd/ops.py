@@ -846,12 +846,12 @@ def gcn_backward(c, dout, extra_add=None, extra_mask=None):
     dypre, dg1, db1, ddpre, dg2, db2 = bn_bwd(dout, c.g_bits, ypre, gamma1, c.g_bn1, dpre, gamma2, c.g_bn2,
                                               sync=c.g_sync, gcount=c.g_count, amax_out=dy_amax)
     x_amax = getattr(c, 'g_x_amax', None)
-    dwd = _side_run(lambda: project_bwd_weight(dypre, x, adj, Cout, dy_amax, x_amax), (dypre, x, adj))
+    dwd = _side_run(lambda: project_bwd_weight(dypre, x, adj, Cout, dy_amax, x_amax), (dypre, x, adj, dy_amax, x_amax))
     dPA = dwab = dbab = dalpha = dtp = dtp_amax = None
     if c.g_adaptive:      # adjacency branch first: its dtp rides along in the dx kernel where that is supported
         dPA, dtp, dbab, dalpha, _, dtp_amax = adjacency_bwd(dypre, wd, x, tp, P, c.g_alpha, wab, c.g_bab,
                                                             dy_amax=dy_amax)
-        dwab = _side_run(lambda: conv_bwd_weight(dtp, x, wab.shape, 1, dtp_amax, x_amax), (dtp, x))
+        dwab = _side_run(lambda: conv_bwd_weight(dtp, x, wab.shape, 1, dtp_amax, x_amax), (dtp, x, dtp_amax, x_amax))
     fuse = dtp is not None and fused_bwd_data_supported(x.shape[1], Cout, x.shape[3])
     ftp = dict(dtp=dtp, wab=wab) if fuse else {}
     ftp['dy_amax'] = dy_amax
@@ -897,6 +897,7 @@ def tcn_forward(c, g, w, b, bn, stride, res_x, res, relu, training, sync=None):
     c.t_sync, c.t_count = sync, gcount
     c.t_bits = bits
     c.t_g, c.t_zpre, c.t_rpre, c.t_out, c.t_bn1, c.t_bn2 = g, zpre, rpre, out, bn1, bn2
+    c.t_g_amax = g_amax
     c.t_resx, c.t_res_identity = res_x, isinstance(res, str)
     c.t_params = (w, bn[0], res[0] if isinstance(res, tuple) else None, res[2] if isinstance(res, tuple) else None)
     c.t_stride, c.t_relu = stride, relu
@@ -911,7 +912,10 @@ def tcn_backward(c, dout, join=True):
     dzpre, dg1, db1, drpre, dg2, db2 = bn_bwd(dout, mask, c.t_zpre, gamma1, c.t_bn1, c.t_rpre, gamma2, c.t_bn2,
                                               sync=c.t_sync, gcount=c.t_count, amax_out=dz_amax)
     t_g, t_stride = c.t_g, c.t_stride
-    dw = _side_run(lambda: conv_bwd_weight(dzpre, t_g, w.shape, t_stride), (dzpre, t_g))
+    t_g_amax = getattr(c, 't_g_amax', None)
+    # (the device scalars are inputs of the side-stream kernels too: dz_amax dies with this frame, possibly before the join)
+    dw = _side_run(lambda: conv_bwd_weight(dzpre, t_g, w.shape, t_stride, dz_amax, t_g_amax),
+                   (dzpre, t_g, dz_amax, t_g_amax))
     dg = conv_bwd_data(dzpre, w, c.t_g.shape, c.t_stride, dy_amax=dz_amax)
     dwres = None
     if drpre is not None:

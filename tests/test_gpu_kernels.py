@@ -407,26 +407,34 @@ def test_sgd_step_matches_torch():
         assert rel(p, p_ref) < 1e-5
 
 
-# N, C(=M), T, V: stride-1 9-tap weight gradient on the split-bf16 kernel (wgrad9_bf16.hip): 64/128-row tiles, ragged
-# last chunk (T % 80 != 0), T not a multiple of 4 (zero padded rows), V = 18
-WGRAD9_CASES = [(2, 64, 23, 25), (2, 128, 85, 25), (3, 64, 300, 18), (2, 256, 75, 25), (1, 128, 150, 25)]
+# N, C(=M), T, V, stride: 9-tap weight gradient on the split-precision kernel (wgrad9_bf16.hip; f16x3 in the default
+# mode): 64/128-row tiles, ragged last chunk (T % 80 != 0), T not a multiple of 4 (zero padded rows), V = 18, stride 2
+WGRAD9_CASES = [(2, 64, 23, 25, 1), (2, 128, 85, 25, 1), (3, 64, 300, 18, 1), (2, 256, 75, 25, 1), (1, 128, 150, 25, 1),
+                (2, 128, 85, 25, 2), (2, 128, 300, 18, 2)]
 
 
 @pytest.mark.parametrize('case', WGRAD9_CASES)
-def test_conv9_weight_gradient_split_bf16(case):
+def test_conv9_weight_gradient_split(case):
     from agcn_amd import ops
     dev = _gpu()
-    N, C, T, V = case
+    N, C, T, V, stride = case
     g = torch.Generator().manual_seed(17 + C + T)
-    x = rnd(g, N, C, T, V)
-    w = rnd(g, C, C, 9, 1, scale=1.0 / np.sqrt(9 * C)).requires_grad_(True)
-    y = F.conv2d(x, w, None, padding=(4, 0))
-    dy = rnd(g, *y.shape)
-    y.backward(dy)
-    dw = ops.conv_bwd_weight(dy.float().to(dev), x.float().to(dev), tuple(w.shape), 1)
-    assert ops._L().agcn_last_kernel().decode().startswith('wgrad9_bf16_kernel') or \
-        ops._L().agcn_gemm_mode().decode() != 'bf16x6'
-    assert rel(dw, w.grad) < TOL
+    L = ops._L()
+    for dy_mag, x_mag in ((1.0, 1.0), (1e-6, 50.0), (3e3, 1e-3)):       # gradients of 1e-6, large activations: range scales
+        x = rnd(g, N, C, T, V) * x_mag
+        w = rnd(g, C, C, 9, 1, scale=1.0 / np.sqrt(9 * C)).requires_grad_(True)
+        y = F.conv2d(x, w, None, stride=(stride, 1), padding=(4, 0))
+        dy = rnd(g, *y.shape) * dy_mag
+        y.backward(dy)
+        dyg, xg = dy.float().to(dev), x.float().to(dev)
+        dw = ops.conv_bwd_weight(dyg, xg, tuple(w.shape), stride)
+        name = L.agcn_last_kernel().decode()
+        assert name.startswith('wgrad9_') or L.agcn_gemm_mode().decode() != 'bf16x6', name
+        assert rel(dw, w.grad) < TOL, (dy_mag, x_mag, rel(dw, w.grad))
+        # the producers' maxima handed in: the same bits as with the kernel's own reduction pass; and on repeats
+        dw2 = ops.conv_bwd_weight(dyg, xg, tuple(w.shape), stride, dyg.abs().max().reshape(1), xg.abs().max().reshape(1))
+        assert torch.equal(dw2, dw)
+        assert torch.equal(ops.conv_bwd_weight(dyg, xg, tuple(w.shape), stride), dw)
 
 
 @pytest.mark.parametrize('case', [(2, 64, 23, 25), (3, 128, 30, 18), (2, 64, 300, 25), (2, 32, 7, 25)])

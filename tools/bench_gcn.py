@@ -62,6 +62,27 @@ for name in layers:
         us = timed(lambda: ops.aggregate_project_bwd_data(dy, adj, w, tuple(x.shape), add1=x, mask1=bits, add2=x, mask2=bits,
                                                           dtp=dtp, wab=wab, dy_amax=amax, dtp_amax=amax))
         out.append(f'bwdf {us:7.0f} us {(proj + aggb + 2.0 * K2 * C * T * V * N) / us / 1e6:6.1f} TF')
+    if 'adj' in which and C >= 16:     # adaptive adjacency forward (theta/phi kept for the backward, max |x| known)
+        Ci = Cout // 4
+        wab = (torch.randn(6 * Ci, C, generator=g) / C ** 0.5).to(dev)
+        bab = torch.zeros(6 * Ci, device=dev)
+        A = torch.zeros(3, V, V, device=dev)
+        amax = x.abs().max().reshape(1)
+        us = timed(lambda: ops.adjacency_fused_fwd(x, wab, bab, A, A, keep_tp=True, x_amax=amax))
+        us2 = timed(lambda: ops.adjacency_fused_fwd(x, wab, bab, A, A, x_amax=amax))
+        fl = 2.0 * 6 * Ci * C * T * V * N + 3 * 2.0 * Ci * T * V * V * N
+        out.append(f'adj {us:7.0f} us (no tp copy {us2:5.0f}) {fl / us / 1e6:6.1f} TF {ops._L().agcn_last_kernel().decode()}')
+    if 'sbwd' in which and C >= 16:    # backward of the scores: dtp from tp and dS
+        Ci = Cout // 4
+        tp = torch.randn(N, 6 * Ci, T, V, generator=g).to(dev)
+        dS = torch.randn(N, 3, V, V, generator=g).to(dev)
+        L = ops._L(); nt = L.agcn_scores_num_tiles(V, T)
+        dtp = torch.empty_like(tp); dbp = torch.empty((N * nt, 6 * Ci), device=dev); db = torch.empty(6 * Ci, device=dev)
+        scr = ops._scratch(6 * Ci, tp); am = torch.empty(1, device=dev)
+        us = timed(lambda: lib.check(L.agcn_adjacency_bwd_scores_ex(lib.ptr(tp), lib.ptr(dS), lib.ptr(dtp), lib.ptr(dbp),
+                                                                    scr.data_ptr(), lib.ptr(db), lib.ptr(am), N, Ci, T, V,
+                                                                    lib.stream()), 'sbwd'))
+        out.append(f'sbwd {us:7.0f} us {2 * tp.numel() * 4 / us / 1e6:5.2f} TB/s {L.agcn_last_kernel().decode()}')
     if 'dadj' in which:
         L = ops._L(); ns = L.agcn_dadj_num_slots(C, V, T)
         dpart = torch.empty((N, 3, ns, V, V), device=dev)
