@@ -166,13 +166,23 @@ adj_bwd_kernel(const float* __restrict__ dpart, const float* __restrict__ P, con
   }
 }
 
-// dPA[i][e] = sum_n dadj[n][i][e]  (fixed order)
-__global__ void dpa_reduce_kernel(const float* __restrict__ dadj, float* __restrict__ dPA, int N, int VV3) {
-  const int e = blockIdx.x * blockDim.x + threadIdx.x;
-  if (e >= VV3) return;
+// dPA[i][e] = sum_n dadj[n][i][e]  (fixed order: four contiguous sample ranges per element, then their sum in range order;
+// 64 elements x 4 ranges per block -- the one-thread-per-element loop over all N samples was 31 us of dependent loads)
+__global__ void __launch_bounds__(256) dpa_reduce_kernel(const float* __restrict__ dadj, float* __restrict__ dPA, int N,
+                                                         int VV3) {
+  __shared__ float part[4][64];
+  const int el = threadIdx.x & 63, grp = threadIdx.x >> 6;
+  const int e = blockIdx.x * 64 + el;
+  const int per = (N + 3) >> 2;
+  const int n0 = grp * per, n1 = min(N, n0 + per);
   float s = 0.f;
-  for (int n = 0; n < N; ++n) s += dadj[(long)n * VV3 + e];
-  dPA[e] = s;
+  if (e < VV3) {
+#pragma unroll 8
+    for (int n = n0; n < n1; ++n) s += dadj[(long)n * VV3 + e];
+  }
+  part[grp][el] = s;
+  __syncthreads();
+  if (grp == 0 && e < VV3) dPA[e] = ((part[0][el] + part[1][el]) + part[2][el]) + part[3][el];
 }
 
 // dtheta_i[c',t,u] = sum_v dS_i[u,v] phi_i[c',t,v];  dphi_i[c',t,v] = sum_u dS_i[u,v] theta_i[c',t,u]
@@ -539,7 +549,7 @@ int agcn_adjacency_bwd_softmax(const float* dadj_part, const float* P, const flo
   int rc = agcn_check_launch();
   if (rc) return rc;
   const int VV3 = 3 * V * V;
-  hipLaunchKernelGGL(dpa_reduce_kernel, dim3((VV3 + 255) / 256), dim3(256), 0, s, (const float*)dadj, dPA, N, VV3);
+  hipLaunchKernelGGL(dpa_reduce_kernel, dim3((VV3 + 63) / 64), dim3(256), 0, s, (const float*)dadj, dPA, N, VV3);
   return agcn_check_launch();
 }
 
