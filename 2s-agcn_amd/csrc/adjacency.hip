@@ -12,6 +12,8 @@
 
 namespace {
 
+typedef unsigned u32x4s __attribute__((ext_vector_type(4)));
+
 constexpr int SC_CK = 16;   // theta/phi channels staged per LDS chunk
 
 __global__ void __launch_bounds__(256)
@@ -398,17 +400,24 @@ scores_bwd_kernel(const float* __restrict__ tp, const float* __restrict__ dS, fl
   }
 }
 
-// The same gradient, one WAVE per (sample, subset, theta|phi, channel) row block and no LDS at all.  A row block is T
-// contiguous rows of V floats, both in tp and in dtp, and the exact-f32 matrix op wants exactly that shape:
-//   dtheta[t, u] = sum_v phi[t, v] dS[u, v]      A = 32 frames x V (lane (t, h) reads element 2s + h of its row: two cache
-//   dphi[t, v]   = sum_u theta[t, u] dS[u, v]    lines' worth of one 32-row run per instruction), B = dS (or its transpose),
-// held in VS registers per lane for the wave's life; D = 32 frames x V joints leaves as 16 stores of two 4V-byte row pieces.
-// The next tile's A operands are in flight while this tile's VS matrix ops run.  Nothing is staged, nothing waits on a
-// barrier; the conv_a/conv_b bias gradient of the row block is one wave reduction at the end (one slot per sample).
+// The same gradient, one WAVE per (sample, subset, theta|phi, channel) row block, no barriers.  A row block is T contiguous
+// rows of V floats, both in tp and in dtp, and the exact-f32 matrix op wants exactly that shape:
+//   dtheta[t, u] = sum_v phi[t, v] dS[u, v]      A = 32 frames x V, B = dS (or its transpose) held in VS registers per lane
+//   dphi[t, v]   = sum_u theta[t, u] dS[u, v]    for the wave's life, D = 32 frames x V joints.
+// A 32-frame tile is 32 V CONTIGUOUS floats on both sides, so it moves as whole 16-byte pieces (range-checked buffer
+// instructions: the ragged last tile needs no masks, what lies past the row block reads as zero and is not written) and
+// changes shape in a wave-private piece of LDS: [32][V] rows -> operand A (lane (t, h) reads element 2s + h of its row,
+// bank-conflict free for odd V) and accumulators -> [32][V] rows -> 16-byte pieces.  (Round 3's first version read and
+// wrote the rows straight from the lanes, 4V-byte pieces of 32 rows per instruction: 3.6 TB/s.)  The next tile's pieces
+// are in flight while this tile's VS matrix ops run; the conv_a/conv_b bias gradient of the row block is one wave
+// reduction at the end (one slot per sample).
 template <int V, int VS>
 __global__ void __launch_bounds__(256) scores_bwd_rows_kernel(const float* __restrict__ tp, const float* __restrict__ dS,
                                                               float* __restrict__ dtp, float* __restrict__ dbpart,
                                                               unsigned* __restrict__ amax, int N, int Ci, int T) {
+  constexpr int TILE = 32 * V;                         // floats of a tile
+  constexpr int NP = (TILE + 255) / 256;               // 16-byte pieces per lane (64 lanes x 4 floats per instruction)
+  __shared__ __attribute__((aligned(16))) float lds[4][2][TILE + 4];
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int lr = lane & 31, h = lane >> 5;
@@ -421,6 +430,8 @@ __global__ void __launch_bounds__(256) scores_bwd_rows_kernel(const float* __res
   const float* src = tp + (which == 0 ? row_ph : row_th) * P;
   float* dst = dtp + (which == 0 ? row_th : row_ph) * P;
   const float* dsn = dS + (long)ni * V * V;
+  float* tin = lds[wave][0];
+  float* tout = lds[wave][1];
   float bq[VS];
 #pragma unroll
   for (int s = 0; s < VS; ++s) {
@@ -431,14 +442,25 @@ __global__ void __launch_bounds__(256) scores_bwd_rows_kernel(const float* __res
   }
   const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(src), 0, (int)(P * 4), 0x00020000);
   const __amdgpu_buffer_rsrc_t rd = __builtin_amdgcn_make_buffer_rsrc(dst, 0, (int)(P * 4), 0x00020000);
-  auto load_a = [&](int t0, float (&av)[VS]) __attribute__((always_inline)) {
-    const int vo = (min(t0 + lr, T - 1) * V + h) * 4;
+  // (a piece that straddles the end of the row block goes dword by dword: the range check of a 16-byte access is not
+  // relied upon to be per dword)
+  auto load_tile = [&](int t0, f32x4 (&pv)[NP]) __attribute__((always_inline)) {
 #pragma unroll
-    for (int s = 0; s < VS; ++s)                       // (element V of a row is the next row's first: masked below; past the
-      av[s] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, vo + 8 * s, 0, 0));   // block: reads 0)
+    for (int u = 0; u < NP; ++u) {
+      const int f = 4 * (lane + 64 * u);               // float of the tile; pieces past the tile are not needed
+      const int o = t0 * V + min(f, TILE - 4);
+      const int rem = (int)P - o;
+      if (rem >= 4) {
+        pv[u] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, o * 4, 0, 0));
+      } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          pv[u][e] = e < rem ? __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, (o + e) * 4, 0, 0)) : 0.f;
+      }
+    }
   };
-  float av[2][VS];
-  load_a(0, av[0]);
+  f32x4 pv[2][NP];
+  load_tile(0, pv[0]);
   float bsum = 0.f;
   unsigned mx = 0;
   const int ntile = (T + 31) >> 5;
@@ -448,28 +470,54 @@ __global__ void __launch_bounds__(256) scores_bwd_rows_kernel(const float* __res
     for (int q = 0; q < 2; ++q) {
       const int t0 = (tb + q) * 32;
       if (t0 < T) {                                    // (wave-uniform)
-        if (t0 + 32 < T) load_a(t0 + 32, av[q ^ 1]);
+        if (t0 + 32 < T) load_tile(t0 + 32, pv[q ^ 1]);
+#pragma unroll
+        for (int u = 0; u < NP; ++u) {
+          const int f = 4 * (lane + 64 * u);
+          if (f < TILE) *reinterpret_cast<f32x4*>(tin + f) = pv[q][u];
+        }
+        __builtin_amdgcn_wave_barrier();
         f32x16 d;
 #pragma unroll
         for (int j = 0; j < 16; ++j) d[j] = 0.f;
 #pragma unroll
         for (int s = 0; s < VS; ++s) {
-          const float a = (2 * s + 1 < V || h == 0) ? av[q][s] : 0.f;
+          const int k = 2 * s + h;
+          float a = tin[lr * V + min(k, V - 1)];
+          a = k < V ? a : 0.f;
           d = mfma32(a, bq[s], d);
         }
         if (lr < V) {
-          const int vo = ((t0 + 4 * h) * V + lr) * 4;  // rows past T fall outside the descriptor: dropped
 #pragma unroll
-          for (int j = 0; j < 16; ++j) {
-            const int rj = (j & 3) + 8 * (j >> 2);
-            const float dj = d[j];                     // (through a float: __builtin_bit_cast on a vector ELEMENT reads element 0)
-            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, dj), rd, vo + rj * V * 4, 0, 0);
-            const bool ok = t0 + 4 * h + rj < T;
-            const float z = ok ? dj : 0.f;
-            bsum += z;
-            mx = max(mx, __float_as_uint(z) & 0x7fffffffu);
+          for (int j = 0; j < 16; ++j) tout[mfma_row(j, h) * V + lr] = d[j];
+        }
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int u = 0; u < NP; ++u) {
+          const int f = 4 * (lane + 64 * u);
+          if (f < TILE) {
+            const f32x4 z = *reinterpret_cast<const f32x4*>(tout + f);
+            const int o = t0 * V + f;
+            const int rem = (int)P - o;                // floats of this piece inside the row block
+            if (rem >= 4) {
+              __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4s, z), rd, o * 4, 0, 0);
+            } else {
+#pragma unroll
+              for (int e = 0; e < 4; ++e) {
+                const float ze = z[e];
+                if (e < rem) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, ze), rd, (o + e) * 4, 0, 0);
+              }
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              const float ze = z[e];
+              const float zz = e < rem ? ze : 0.f;       // (rows past the block are not part of the sums)
+              bsum += zz;
+              mx = max(mx, __float_as_uint(zz) & 0x7fffffffu);
+            }
           }
         }
+        __builtin_amdgcn_wave_barrier();               // (tout / tin are rewritten by the next tile)
       }
     }
   }
