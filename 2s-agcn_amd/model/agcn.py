@@ -8,8 +8,10 @@ arguments, ``forward(x)`` with x of shape (N, C, T, V, M), parameter/buffer name
 
 Underneath, every operator of unit_gcn / unit_tcn runs as a hand-written gfx950 HIP kernel through the
 C-ABI in ``libagcn_hip.so`` (see ``ops.py``).  There is no CPU / stock-PyTorch fallback for them: a CPU tensor
-or a missing extension raises.  Only the tiny model prologue/epilogue (data_bn on (N, M*V*C, T), the global
-average pool and the 256->num_class Linear; reference agcn.py:163-165,179-183) use stock PyTorch operators.
+or a missing extension raises.  The model prologue/epilogue (data_bn on (N, M*V*C, T), the global average pool and
+the 256->num_class Linear; reference agcn.py:163-165,179-183) run on deterministic HIP entry points as well
+(``agcn_data_bn_*``, ``agcn_pool_*``, ``agcn_linear_*``: csrc/small_ops.hip) -- the stock operators were the one source of
+run-to-run differences between processes.
 """
 import math
 

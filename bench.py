@@ -264,8 +264,12 @@ def unit_gcn_forward_roofline(device, reps=5, Np=128, V=25):
         Ci = Cout // 4
         fused_adj = ops.adjacency_fused_supported(C, Ci, T, V)
         chained = C >= 32 and mode != 'f32'
+        # theta/phi of the layers the persistent adjacency kernel takes (csrc/adj_ws.hip: Ci <= 32) run on f16x3
+        adj_ws = fused_adj and mode != 'f32' and chain_mode == 'f16x3' and Ci in (16, 32) and C in (64, 128) \
+            and os.environ.get('AGCN_ADJ_WS', '1') != '0'
         ph = {  # phase: (FLOPs, peak TFLOP/s of the arithmetic it runs in)
-            'theta_phi': (Np * 6 * 2 * C * Ci * T * V, split_peak if fused_adj else PEAK_FP32_MFMA_TFLOPS),
+            'theta_phi': (Np * 6 * 2 * C * Ci * T * V,
+                          chain_peak if adj_ws else (split_peak if fused_adj else PEAK_FP32_MFMA_TFLOPS)),
             'scores': (Np * 3 * 2 * V * V * Ci * T, PEAK_FP32_MFMA_TFLOPS),
             'aggregate': (Np * 3 * 2 * C * T * V * V, chain_peak if chained and chain_agg_split else PEAK_FP32_MFMA_TFLOPS),
             'project': (Np * 3 * 2 * C * Cout * T * V, chain_peak if chained else PEAK_FP32_MFMA_TFLOPS),
