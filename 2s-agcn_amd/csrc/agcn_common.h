@@ -96,7 +96,8 @@ bool agcn_gcn_dadj_chain_supported(int C, int V);
 int agcn_gcn_dadj_chain_slots(int C, int T);
 size_t agcn_gcn_dadj_chain_workspace(int C, int Cout);
 int agcn_gcn_dadj_chain(const float* dy, const float* wcat, const float* x, float* dadj_part, void* ws, size_t ws_bytes,
-                        int N, int C, int Cout, int T, int V, hipStream_t stream, const float* dy_absmax = nullptr);
+                        int N, int C, int Cout, int T, int V, hipStream_t stream, const float* dy_absmax = nullptr,
+                        const float* x_absmax = nullptr);
 
 // split-bf16 weight gradients of the tap-free contractions (wgrad_chain.hip): partial slabs only, reduced by the caller
 bool agcn_wgrad_chain_supported(int M, int C, int V);

@@ -870,19 +870,22 @@ int agcn_gcn_aggregate_project_bwd_data_fused(const float* dy, const float* adj,
 
 // dadj_part[n][i][slot][u][v] = sum over the slot's (c,t) of x[n][c][t,u] * (sum_o wcat[o][i*C+c] dy[n][o][t,v])
 int agcn_gcn_dadj_ex(const float* dy, const float* wcat, const float* x, float* dadj_part, void* workspace,
-                     size_t workspace_bytes, int N, int C, int Cout, int T, int V, const float* dy_absmax, void* stream);
+                     size_t workspace_bytes, int N, int C, int Cout, int T, int V, const float* dy_absmax,
+                     const float* x_absmax, void* stream);
 int agcn_gcn_dadj(const float* dy, const float* wcat, const float* x, float* dadj_part, void* workspace,
                   size_t workspace_bytes, int N, int C, int Cout, int T, int V, void* stream) {
-  return agcn_gcn_dadj_ex(dy, wcat, x, dadj_part, workspace, workspace_bytes, N, C, Cout, T, V, nullptr, stream);
+  return agcn_gcn_dadj_ex(dy, wcat, x, dadj_part, workspace, workspace_bytes, N, C, Cout, T, V, nullptr, nullptr, stream);
 }
-// dy_absmax: device scalar max |dy| (agcn_bn_bwd_apply_ex) for the f16x3 projection; null: a streaming pass inside
+// dy_absmax: device scalar max |dy| (agcn_bn_bwd_apply_ex) for the f16x3 projection; null: a streaming pass inside.
+// x_absmax: device scalar max |x| (kept by the forward) for the f16x3 reduction against x; null: a streaming pass inside
 int agcn_gcn_dadj_ex(const float* dy, const float* wcat, const float* x, float* dadj_part, void* workspace,
-                     size_t workspace_bytes, int N, int C, int Cout, int T, int V, const float* dy_absmax, void* stream) {
+                     size_t workspace_bytes, int N, int C, int Cout, int T, int V, const float* dy_absmax,
+                     const float* x_absmax, void* stream) {
   if (!dy || !wcat || !x || !dadj_part || !workspace || N <= 0 || C <= 0 || Cout <= 0 || T <= 0 || V <= 0 || V > 32)
     return AGCN_ERR_ARG;
   if (agcn_chained() && agcn_gcn_dadj_chain_supported(C, V))
     return agcn_gcn_dadj_chain(dy, wcat, x, dadj_part, workspace, workspace_bytes, N, C, Cout, T, V, (hipStream_t)stream,
-                               dy_absmax);
+                               dy_absmax, x_absmax);
   if (C >= 64 && C % 64 != 0) return AGCN_ERR_UNSUPPORTED;
   Problem p = {};
   ConvGemmArgs& a = p.a;

@@ -1300,6 +1300,8 @@ struct DadjArgs {
   int ntiles, nkc, nmb, nslots, gpc;   // gpc = row blocks per subset (C / BM)
   int npl;                     // 3: six split products (bf16x6) ; 1: hi*hi only (bf16)
   const float* dy_absmax;      // f16x3: device scalar max |dy| for the range scale
+  const float* x_absmax;       // f16x3 reduction against x (null: exact-f32 reduction MFMA)
+  int dbg;                     // AGCN_DADJ_DBG profiling switches (1: no reduction phase, 2: no projection MFMAs)
 };
 
 struct DadjPackArgs {
@@ -1356,7 +1358,21 @@ __global__ void __launch_bounds__(NW * 64, 2) gcn_dadj_chain_kernel(const DadjAr
   const int PT = FT * V;                               // positions of the frame tile
   const int B_IMG = PL * 4 * PT * 16;                  // bytes: [plane][ks][h][pos][8]
   float rs_s = 1.f, rs_inv = 1.f;
-  if constexpr (F16) { f16_range_scale(a.dy_absmax, rs_s, rs_inv); rs_inv *= F16_W_INV; }
+  // F16 with max |x| known: the reduction against x runs on f16x3 as well.  H = Wd_i^T dy is then split straight out of the
+  // accumulators, so dy is scaled to 2^F16_ADJ_TARGET instead of 2^14: |H'| <= 2^(8 + TARGET + 1) * sum_o |w_oc| stays inside
+  // fp16 for column sums of |Wd| below 32 (the reference's conv_d weights: ~1 at 64 channels, ~1-3 at 256; beyond: Inf -> NaN,
+  // visible).  x is scaled to 2^14 like every directly split operand.
+  const bool red16 = F16 && a.x_absmax != nullptr;     // kernel-uniform
+  float xs = 1.f, xinv = 1.f;
+  if constexpr (F16) {
+    if (red16) {
+      f16_range_scale_of<F16_ADJ_TARGET>(*a.dy_absmax, rs_s, rs_inv);
+      f16_range_scale_of<14>(*a.x_absmax, xs, xinv);
+    } else {
+      f16_range_scale(a.dy_absmax, rs_s, rs_inv);
+    }
+    rs_inv *= F16_W_INV * xinv;
+  }
   unsigned char* abuf = smem;                          // [2][A_IMG]
   unsigned char* bbuf = smem + 2 * A_IMG;              // [2][B_IMG]
 
@@ -1464,7 +1480,7 @@ __global__ void __launch_bounds__(NW * 64, 2) gcn_dadj_chain_kernel(const DadjAr
     if (s + 1 < S) commit(s + 1);
     if (s + 2 < S) issue(s + 2);
     if (s == S - 1) load_x(0, xa0);
-    if (fvalid) {
+    if (fvalid && !(a.dbg & 2)) {
       const unsigned char* ab = abuf + (s & 1) * A_IMG + lane * 16;
       const unsigned char* bb = bbuf + (s & 1) * B_IMG;
 #pragma unroll
@@ -1503,11 +1519,35 @@ __global__ void __launch_bounds__(NW * 64, 2) gcn_dadj_chain_kernel(const DadjAr
   f32x16 d;
 #pragma unroll
   for (int j = 0; j < 16; ++j) d[j] = 0.f;
-  if (fvalid) {
+  if (fvalid && !(a.dbg & 1)) {
     float xb[2][16];
 #pragma unroll
     for (int tm = 0; tm < TM; ++tm) {
       if (tm + 1 < TM) load_x(tm + 1, xb[(tm + 1) & 1]);          // next tile's operands in flight during this tile
+      if (F16 && red16) {
+        // k index e of step ks <-> D register 8 ks + e of this half: the accumulators ARE the B fragments once split, and
+        // load_x fetched x in the same register order
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+          u32x4 ah, al, bh, bl;
+#pragma unroll
+          for (int e2 = 0; e2 < 4; ++e2) {
+            const int j = 8 * ks + 2 * e2;
+            float x0 = (tm == 0) ? xa0[j] : xb[tm & 1][j];
+            float x1 = (tm == 0) ? xa0[j + 1] : xb[tm & 1][j + 1];
+            x0 = (lr < V) ? x0 * xs : 0.f;
+            x1 = (lr < V) ? x1 * xs : 0.f;
+            unsigned p0, p1, q0, q1;
+            split_pair_f16_mix(x0, x1, p0, p1);
+            split_pair_f16_mix(acc[tm][j], acc[tm][j + 1], q0, q1);
+            ah[e2] = p0; al[e2] = p1; bh[e2] = q0; bl[e2] = q1;
+          }
+          d = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, al), __builtin_bit_cast(f16x8, bh), d, 0, 0, 0);
+          d = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, ah), __builtin_bit_cast(f16x8, bl), d, 0, 0, 0);
+          d = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, ah), __builtin_bit_cast(f16x8, bh), d, 0, 0, 0);
+        }
+        continue;
+      }
 #pragma unroll
       for (int j = 0; j < 16; ++j) {
         const float xv = (tm == 0) ? xa0[j] : xb[tm & 1][j];
@@ -1557,6 +1597,14 @@ int dadj_chain_launch(DadjArgs a, const float* wcat, void* ws, size_t ws_bytes, 
       unsigned* amax = reinterpret_cast<unsigned*>(static_cast<char*>(ws) + pack_bytes);
       if (int rc = agcn_launch_absmax(a.dy, (long)a.N * a.Cout * a.T * a.V, amax, stream)) return rc;
       a.dy_absmax = reinterpret_cast<const float*>(amax);
+    }
+    static const int red16 = getenv("AGCN_DADJ_RED16") ? atoi(getenv("AGCN_DADJ_RED16")) : 1;   // 0: exact-f32 reduction (A/B)
+    if (!red16) {
+      a.x_absmax = nullptr;
+    } else if (!a.x_absmax) {  // the same arithmetic with or without the producer's maximum: a pass of our own
+      unsigned* amax = reinterpret_cast<unsigned*>(static_cast<char*>(ws) + pack_bytes) + 1;
+      if (int rc = agcn_launch_absmax(a.x, (long)a.N * a.C * a.T * a.V, amax, stream)) return rc;
+      a.x_absmax = reinterpret_cast<const float*>(amax);
     }
   }
   DadjPackArgs pk;
@@ -1670,11 +1718,14 @@ size_t agcn_gcn_dadj_chain_workspace(int C, int Cout) {
 }
 
 int agcn_gcn_dadj_chain(const float* dy, const float* wcat, const float* x, float* dadj_part, void* ws, size_t ws_bytes,
-                        int N, int C, int Cout, int T, int V, hipStream_t stream, const float* dy_absmax) {
+                        int N, int C, int Cout, int T, int V, hipStream_t stream, const float* dy_absmax,
+                        const float* x_absmax) {
   DadjArgs a = {};
   a.npl = agcn_npl();
   a.dy = dy; a.x = x; a.dpart = dadj_part; a.N = N; a.C = C; a.Cout = Cout; a.T = T; a.V = V;
   a.dy_absmax = dy_absmax;
+  a.x_absmax = x_absmax;       // (null: taken by a pass inside; AGCN_DADJ_RED16=0: exact-f32 reduction MFMA)
+  if (const char* e = getenv("AGCN_DADJ_DBG")) a.dbg = atoi(e);
   static const int f16 = getenv("AGCN_DADJ_F16X3") ? atoi(getenv("AGCN_DADJ_F16X3")) : 1;   // 0: bf16x6 (A/B)
   if (agcn_chain_f16x3() && f16) {
     if (C % 128 == 0) return dadj_chain_launch<4, DADJ_NW, true>(a, wcat, ws, ws_bytes, stream);

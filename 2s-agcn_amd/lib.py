@@ -41,7 +41,7 @@ SIGNATURES = {
     "agcn_gcn_aggregate_project_fwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _Z, _I, _I, _I, _I, _I, _P]),
     "agcn_gcn_aggregate_project_fwd_ex": (_I, [_P, _P, _P, _P, _P, _P, _P, _Z, _I, _I, _I, _I, _I, _P, _P]),
     "agcn_gcn_aggregate_project_bwd_data_ex": (_I, [_P, _P, _P, _P, _P, _I, _P, _I, _P, _P, _P, _P, _I, _P, _Z, _I, _I, _I, _I, _I, _P, _P, _P]),
-    "agcn_gcn_dadj_ex": (_I, [_P, _P, _P, _P, _P, _Z, _I, _I, _I, _I, _I, _P, _P]),
+    "agcn_gcn_dadj_ex": (_I, [_P, _P, _P, _P, _P, _Z, _I, _I, _I, _I, _I, _P, _P, _P]),
     "agcn_adjacency_bwd_scores_ex": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
     "agcn_conv_bwd_weight_ex": (_I, [_P, _P, _P, _P, _Z, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P]),
     "agcn_gcn_project_bwd_weight_ex": (_I, [_P, _P, _P, _P, _P, _Z, _I, _I, _I, _I, _I, _P, _P, _P]),

@@ -299,7 +299,7 @@ def project_bwd_weight(dy, x, adj, Cout, dy_amax=None, x_amax=None):
     return dw
 
 
-def adjacency_bwd(dy, wcat, x, tp, P, alpha=None, wab=None, bab=None, dy_amax=None):
+def adjacency_bwd(dy, wcat, x, tp, P, alpha=None, wab=None, bab=None, dy_amax=None, x_amax=None):
     """Gradient of the adaptive adjacency branch.  Returns dPA (3,V,V), dtp (N,6Ci,T,V), dbab (6Ci), dalpha, dadj and
     the device scalar max |dtp| its producer left behind (None where it does not: the consumers take it themselves).
     tp = None: theta/phi were never stored (adjacency_fused_fwd); they are recomputed from x, wab, bab on chip."""
@@ -310,7 +310,7 @@ def adjacency_bwd(dy, wcat, x, tp, P, alpha=None, wab=None, bab=None, dy_amax=No
     dpart = _empty((N, 3, nslots, V, V), x)
     ws, nb = _gcn_ws(C, Cout, T, V, x)
     _lib.check(_L().agcn_gcn_dadj_ex(_lib.ptr(dy), _lib.ptr(wcat), _lib.ptr(x), _lib.ptr(dpart), ws.data_ptr(), nb, N, C,
-                                     Cout, T, V, _lib.ptr(dy_amax), _lib.stream()), "agcn_gcn_dadj")
+                                     Cout, T, V, _lib.ptr(dy_amax), _lib.ptr(x_amax), _lib.stream()), "agcn_gcn_dadj")
     dadj = _empty((N, 3, V, V), x)
     dS = _empty((N, 3, V, V), x)
     dPA = _empty((3, V, V), x)
@@ -850,7 +850,7 @@ def gcn_backward(c, dout, extra_add=None, extra_mask=None):
     dPA = dwab = dbab = dalpha = dtp = dtp_amax = None
     if c.g_adaptive:      # adjacency branch first: its dtp rides along in the dx kernel where that is supported
         dPA, dtp, dbab, dalpha, _, dtp_amax = adjacency_bwd(dypre, wd, x, tp, P, c.g_alpha, wab, c.g_bab,
-                                                            dy_amax=dy_amax)
+                                                            dy_amax=dy_amax, x_amax=x_amax)
         dwab = _side_run(lambda: conv_bwd_weight(dtp, x, wab.shape, 1, dtp_amax, x_amax), (dtp, x, dtp_amax, x_amax))
     fuse = dtp is not None and fused_bwd_data_supported(x.shape[1], Cout, x.shape[3])
     ftp = dict(dtp=dtp, wab=wab) if fuse else {}

@@ -107,7 +107,8 @@ int agcn_gcn_aggregate_project_bwd_data_ex(const float* dy, const float* adj, co
                                            void* workspace, size_t workspace_bytes, int N, int C, int Cout, int T, int V,
                                            const float* dy_absmax, const float* dtp_absmax, void* stream);
 int agcn_gcn_dadj_ex(const float* dy, const float* wcat, const float* x, float* dadj_part, void* workspace,
-                     size_t workspace_bytes, int N, int C, int Cout, int T, int V, const float* dy_absmax, void* stream);
+                     size_t workspace_bytes, int N, int C, int Cout, int T, int V, const float* dy_absmax,
+                     const float* x_absmax, void* stream);
 int agcn_adjacency_bwd_scores_ex(const float* tp, const float* dS, float* dtp, float* dbpart, void* scratch, float* db,
                                  float* dtp_absmax_out, int N, int Ci, int T, int V, void* stream);
 /* weight gradients: with BOTH operand maxima given the tap-free gradients (1x1, stride 1, Cin a multiple of 64; the

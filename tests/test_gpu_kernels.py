@@ -662,9 +662,14 @@ def test_f16x3_range_scaling(case):
     nslots = L.agcn_dadj_num_slots(C, V, T)
     dpart = torch.empty((N, 3, nslots, V, V), device=dev)
     ws, nb = ops._gcn_ws(C, Cout, T, V, xg)
-    lib.check(L.agcn_gcn_dadj_ex(lib.ptr(dyg), lib.ptr(wg), lib.ptr(xg), lib.ptr(dpart), ws.data_ptr(), nb, N, C, Cout, T,
-                                 V, lib.ptr(dy_amax), lib.stream()), 'dadj')
-    assert _rel_strict(dpart.sum(2), adj.grad) < tol
+    for xm in (None, x_amax):           # max |x| taken by a pass inside / handed in: the same bits
+        lib.check(L.agcn_gcn_dadj_ex(lib.ptr(dyg), lib.ptr(wg), lib.ptr(xg), lib.ptr(dpart), ws.data_ptr(), nb, N, C, Cout,
+                                     T, V, lib.ptr(dy_amax), lib.ptr(xm), lib.stream()), 'dadj')
+        assert _rel_strict(dpart.sum(2), adj.grad) < tol, (xm is not None, _rel_strict(dpart.sum(2), adj.grad))
+        if xm is None:
+            first = dpart.clone()
+        else:
+            assert torch.equal(dpart, first)
     # temporal convolution (forward and backward-data run on f16x3 too)
     w9 = rnd(g, Cout, C, 9, 1, scale=1.0 / np.sqrt(9 * C))
     z_ref = torch.nn.functional.conv2d(x.detach(), w9, None, padding=(4, 0))

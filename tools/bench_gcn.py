@@ -87,8 +87,10 @@ for name in layers:
         L = ops._L(); ns = L.agcn_dadj_num_slots(C, V, T)
         dpart = torch.empty((N, 3, ns, V, V), device=dev)
         ws, nb = ops._gcn_ws(C, Cout, T, V, x)
-        us = timed(lambda: lib.check(L.agcn_gcn_dadj(lib.ptr(dy), lib.ptr(w), lib.ptr(x), lib.ptr(dpart), ws.data_ptr(),
-                                                     nb, N, C, Cout, T, V, lib.stream()), 'dadj'))
+        am_dy, am_x = dy.abs().max().reshape(1), x.abs().max().reshape(1)     # (left behind by the producers in the step)
+        us = timed(lambda: lib.check(L.agcn_gcn_dadj_ex(lib.ptr(dy), lib.ptr(w), lib.ptr(x), lib.ptr(dpart), ws.data_ptr(),
+                                                        nb, N, C, Cout, T, V, lib.ptr(am_dy), lib.ptr(am_x), lib.stream()),
+                                     'dadj'))
         out.append(f'dadj {us:7.0f} us {(proj + agg) / us / 1e6:6.1f} TF')
     if 'wgrad' in which:
         us = timed(lambda: ops.project_bwd_weight(dy, x, adj, Cout))
