@@ -314,7 +314,6 @@ __global__ void __launch_bounds__(NW * 64, 2) wgrad_chain_kernel(const WcArgs a)
 // column sums) while the consumers split it; the slabs are un-scaled when stored.
 template <int AGG, int TM, int NCB, int VS, int NRB = 1, int NWC = 8, int NWP = 4, bool F16 = false>
 __global__ void __launch_bounds__((NWC + NWP) * 64, (NWC + NWP) / 4) wgrad_pc_kernel(const WcArgs a) {
-  static_assert(!F16 || !(AGG && VS == 0), "the f16x3 variant keeps the aggregation on the exact-f32 chain");
   constexpr int PL = F16 ? 2 : 3, NPROD = F16 ? 3 : 6;
   constexpr int NTP = NWP * 64, BM = TM * 32 * NRB;
   constexpr int NS = AGG ? 3 : 1;
@@ -335,8 +334,12 @@ __global__ void __launch_bounds__((NWC + NWP) * 64, (NWC + NWP) / 4) wgrad_pc_ke
   }
   // VS == 0: the aggregation chain runs on split-bf16 MFMA (12 MFMAs of 32 cycles for K = 32 joints instead of VS
   // exact-f32 steps of 64 cycles): adjacencies kept as bf16 planes [subset][plane][ks][h][v][8 u] (gcn_chain.hip)
+  // F16 with VS == 0: the aggregation on f16x3 as well (6 MFMAs of 32 cycles instead of 13 x 64: the exact-f32 chain was
+  // two thirds of the consumers' matrix-pipe time): x is scaled to 2^F16_ADJ_TARGET BEFORE the aggregation, G comes out
+  // scaled and is split as it is; adjacencies as two fp16 planes
   constexpr bool BCH = AGG && VS == 0;
-  constexpr int ADJ_BYTES = !AGG ? 0 : (BCH ? 3 * 3 * 2 * 2 * 32 * 16 : 3 * 32 * 32 * 4);
+  constexpr int PLA = F16 ? 2 : 3;                   // adjacency planes
+  constexpr int ADJ_BYTES = !AGG ? 0 : (BCH ? 3 * PLA * 2 * 2 * 32 * 16 : 3 * 32 * 32 * 4);
   const int BUF_BYTES = DY_BYTES + ((CG * XP * 4 + 15) & ~15) + ADJ_BYTES;
   const long Pout = (long)a.T_out * V, Psrc = (long)a.T_src * V;
 
@@ -470,12 +473,13 @@ __global__ void __launch_bounds__((NWC + NWP) * 64, (NWC + NWP) / 4) wgrad_pc_ke
               const float tv = adjn[ok ? ((sub * V + u) * V + col) : 0];
               vv[q] = ok ? tv : 0.f;
             }
-            unsigned q0, q1, q2;
-            wc_split_pair(vv[0], vv[1], q0, q1, q2);
+            unsigned q0, q1, q2 = 0;
+            if constexpr (F16) split_pair_f16(vv[0], vv[1], q0, q1);
+            else wc_split_pair(vv[0], vv[1], q0, q1, q2);
             const int o = (((ks * 2 + hh) * 32) + col) * 16 + e2 * 4;
-            *reinterpret_cast<unsigned*>(adjq + (sub * 3 + 0) * 2048 + o) = q0;
-            *reinterpret_cast<unsigned*>(adjq + (sub * 3 + 1) * 2048 + o) = q1;
-            *reinterpret_cast<unsigned*>(adjq + (sub * 3 + 2) * 2048 + o) = q2;
+            *reinterpret_cast<unsigned*>(adjq + (sub * PLA + 0) * 2048 + o) = q0;
+            *reinterpret_cast<unsigned*>(adjq + (sub * PLA + 1) * 2048 + o) = q1;
+            if constexpr (!F16) *reinterpret_cast<unsigned*>(adjq + (sub * PLA + 2) * 2048 + o) = q2;
           }
         }
       }
@@ -549,27 +553,38 @@ __global__ void __launch_bounds__((NWC + NWP) * 64, (NWC + NWP) / 4) wgrad_pc_ke
           } else {
             // G^T = A^_sub^T . x^T: A operand = adjacency planes (row v = lane), B operand = this lane's channel, joints
             // 16 ks + 8 h + e (beyond V: finite neighbours that meet the zero rows of the adjacency)
-            const unsigned char* aq = dyi + BUF_BYTES - ADJ_BYTES + sub * 3 * 2048 + (h * 32 + lr) * 16;
+            const unsigned char* aq = dyi + BUF_BYTES - ADJ_BYTES + sub * PLA * 2048 + (h * 32 + lr) * 16;
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) {
               u32x4 qh, qm, ql;
 #pragma unroll
               for (int e2 = 0; e2 < 4; ++e2) {
-                unsigned q0, q1, q2;
-                wc_split_pair(xrs[16 * ks + 8 * h + 2 * e2], xrs[16 * ks + 8 * h + 2 * e2 + 1], q0, q1, q2);
+                unsigned q0, q1, q2 = 0;
+                const float xa = xrs[16 * ks + 8 * h + 2 * e2], xb2 = xrs[16 * ks + 8 * h + 2 * e2 + 1];
+                if constexpr (F16) split_pair_f16_mix(xa * s_x, xb2 * s_x, q0, q1);
+                else wc_split_pair(xa, xb2, q0, q1, q2);
                 qh[e2] = q0; qm[e2] = q1; ql[e2] = q2;
               }
-              const bf16x8 x0 = __builtin_bit_cast(bf16x8, qh), x1 = __builtin_bit_cast(bf16x8, qm),
-                           x2 = __builtin_bit_cast(bf16x8, ql);
-              const bf16x8 a0 = *reinterpret_cast<const bf16x8*>(aq + 0 * 2048 + ks * 1024);
-              const bf16x8 a1 = *reinterpret_cast<const bf16x8*>(aq + 1 * 2048 + ks * 1024);
-              const bf16x8 a2 = *reinterpret_cast<const bf16x8*>(aq + 2 * 2048 + ks * 1024);
-              d = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, x0, d, 0, 0, 0);
-              d = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, x2, d, 0, 0, 0);
-              d = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, x1, d, 0, 0, 0);
-              d = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, x0, d, 0, 0, 0);
-              d = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, x1, d, 0, 0, 0);
-              d = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, x0, d, 0, 0, 0);
+              if constexpr (F16) {
+                const f16x8 x0 = __builtin_bit_cast(f16x8, qh), x1 = __builtin_bit_cast(f16x8, qm);
+                const f16x8 a0 = *reinterpret_cast<const f16x8*>(aq + 0 * 2048 + ks * 1024);
+                const f16x8 a1 = *reinterpret_cast<const f16x8*>(aq + 1 * 2048 + ks * 1024);
+                d = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, x0, d, 0, 0, 0);
+                d = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, x1, d, 0, 0, 0);
+                d = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, x0, d, 0, 0, 0);
+              } else {
+                const bf16x8 x0 = __builtin_bit_cast(bf16x8, qh), x1 = __builtin_bit_cast(bf16x8, qm),
+                             x2 = __builtin_bit_cast(bf16x8, ql);
+                const bf16x8 a0 = *reinterpret_cast<const bf16x8*>(aq + 0 * 2048 + ks * 1024);
+                const bf16x8 a1 = *reinterpret_cast<const bf16x8*>(aq + 1 * 2048 + ks * 1024);
+                const bf16x8 a2 = *reinterpret_cast<const bf16x8*>(aq + 2 * 2048 + ks * 1024);
+                d = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, x0, d, 0, 0, 0);
+                d = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, x2, d, 0, 0, 0);
+                d = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, x1, d, 0, 0, 0);
+                d = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, x0, d, 0, 0, 0);
+                d = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, x1, d, 0, 0, 0);
+                d = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, x0, d, 0, 0, 0);
+              }
             }
           }
         } else {
@@ -588,7 +603,8 @@ __global__ void __launch_bounds__((NWC + NWP) * 64, (NWC + NWP) / 4) wgrad_pc_ke
 #pragma unroll
           for (int e2 = 0; e2 < 4; ++e2) {
             unsigned q0, q1, q2 = 0;
-            if constexpr (F16) split_pair_f16(d[8 * ks + 2 * e2] * s_x, d[8 * ks + 2 * e2 + 1] * s_x, q0, q1);
+            if constexpr (F16 && BCH) split_pair_f16_mix(d[8 * ks + 2 * e2], d[8 * ks + 2 * e2 + 1], q0, q1);   // (G carries s_x)
+            else if constexpr (F16) split_pair_f16(d[8 * ks + 2 * e2] * s_x, d[8 * ks + 2 * e2 + 1] * s_x, q0, q1);
             else wc_split_pair(d[8 * ks + 2 * e2], d[8 * ks + 2 * e2 + 1], q0, q1, q2);
             gh[e2] = q0; gm[e2] = q1; gl[e2] = q2;
           }
@@ -761,7 +777,7 @@ WcGeom wc_geom_pc(int N, int M, int C, int V, int T_out, bool bch = false, int p
   g.nmb = (M + BM - 1) / BM;
   g.XP = (FT * V) | 1;
   g.smem_bytes = 2 * ((size_t)planes * FT * 4 * (BM + 1) * 16 + (((size_t)CG * g.XP * 4 + 15) & ~(size_t)15) +
-                      (AGG ? (bch ? (size_t)3 * 3 * 2 * 2 * 32 * 16 : (size_t)3 * 32 * 32 * 4) : 0)) + 32;
+                      (AGG ? (bch ? (size_t)3 * planes * 2 * 2 * 32 * 16 : (size_t)3 * 32 * 32 * 4) : 0)) + 32;
   g.grid_x = g.nmb * g.ncg;
   const int pairs = N * g.ntiles;
   int want = 256 / g.grid_x;                   // one 12-wave workgroup per CU
@@ -781,10 +797,10 @@ static inline bool wc_f16x3() {
 
 template <int AGG, int TM, int NCB, int NRB, int VS, int NWP = 4>
 int wc_launch_pc(WcArgs a, void* ws, size_t ws_bytes, int* nslabs_out, hipStream_t stream) {
-  // f16x3 when the caller supplied both operand maxima (fp32-equivalent mode, exact-f32 aggregation chain)
-  if constexpr (!(AGG && VS == 0)) {
+  // f16x3 when the caller supplied both operand maxima (fp32-equivalent mode); VS == 0: the aggregation on f16x3 too
+  {
     if (a.dy_absmax && a.in_absmax && a.npl == 3 && wc_f16x3()) {
-      const WcGeom g = wc_geom_pc<AGG, TM, NCB, NRB>(a.N, a.M, a.C, a.V, a.T_out, false, 2);
+      const WcGeom g = wc_geom_pc<AGG, TM, NCB, NRB>(a.N, a.M, a.C, a.V, a.T_out, AGG && VS == 0, 2);
       if (g.smem_bytes > 160 * 1024) return AGCN_ERR_UNSUPPORTED;
       if ((size_t)g.nslabs * a.wsize * 4 > ws_bytes) return AGCN_ERR_WORKSPACE;
       a.part = (float*)ws;
@@ -822,6 +838,10 @@ int wc_dispatch_pc_vs(const WcArgs& a, void* ws, size_t ws_bytes, int* nslabs, h
     // and becomes VALU-bound; AGCN_WC_BCH=1 selects it)
     static const int bch = getenv("AGCN_WC_BCH") ? atoi(getenv("AGCN_WC_BCH")) : 0;
     if (bch && a.npl == 3) return wc_launch_pc<AGG, TM, NCB, NRB, 0>(a, ws, ws_bytes, nslabs, s);
+    // with both maxima: the aggregation on f16x3 as well (AGCN_WC_AGG16=0: exact-f32 aggregation chain, round 2)
+    static const int agg16 = getenv("AGCN_WC_AGG16") ? atoi(getenv("AGCN_WC_AGG16")) : 1;
+    if (agg16 && a.dy_absmax && a.in_absmax && a.npl == 3 && wc_f16x3())
+      return wc_launch_pc<AGG, TM, NCB, NRB, 0>(a, ws, ws_bytes, nslabs, s);
     if (vs == 13) return wc_launch_pc<AGG, TM, NCB, NRB, 13>(a, ws, ws_bytes, nslabs, s);
     if (vs == 9) return wc_launch_pc<AGG, TM, NCB, NRB, 9>(a, ws, ws_bytes, nslabs, s);
     return wc_launch_pc<AGG, TM, NCB, NRB, 16>(a, ws, ws_bytes, nslabs, s);

@@ -93,8 +93,9 @@ for name in layers:
                                      'dadj'))
         out.append(f'dadj {us:7.0f} us {(proj + agg) / us / 1e6:6.1f} TF')
     if 'wgrad' in which:
-        us = timed(lambda: ops.project_bwd_weight(dy, x, adj, Cout))
-        out.append(f'wgrad {us:7.0f} us {(proj + agg) / us / 1e6:6.1f} TF')
+        am_dy2, am_x2 = dy.abs().max().reshape(1), x.abs().max().reshape(1)   # (left behind by the producers in the step)
+        us = timed(lambda: ops.project_bwd_weight(dy, x, adj, Cout, am_dy2, am_x2))
+        out.append(f'wgrad {us:7.0f} us {(proj + agg) / us / 1e6:6.1f} TF {ops._L().agcn_last_kernel().decode()}')
     if 'w1' in which:     # 1x1 weight gradient at the shape of the fused conv_a/conv_b projection (M = 6*Cout/4 rows)
         M1 = 6 * (Cout // 4)
         dy1 = torch.randn(N, M1, T, V, generator=g).to(dev)
