@@ -340,7 +340,10 @@ __global__ void __launch_bounds__((NWC + NWP) * 64, (NWC + NWP) / 4) wgrad_pc_ke
   constexpr bool BCH = AGG && VS == 0;
   constexpr int PLA = F16 ? 2 : 3;                   // adjacency planes
   constexpr int ADJ_BYTES = !AGG ? 0 : (BCH ? 3 * PLA * 2 * 2 * 32 * 16 : 3 * 32 * 32 * 4);
-  const int BUF_BYTES = DY_BYTES + ((CG * XP * 4 + 15) & ~15) + ADJ_BYTES;
+  // BCH: the last frame's 32-joint fragment of the last x row runs up to 32 - V floats past the row: slack, zeroed once
+  // (what it meets is a zero row of the adjacency, but stale bits must not turn into Inf / NaN when converted to fp16)
+  constexpr int XSLACK = BCH ? 128 : 0;
+  const int BUF_BYTES = DY_BYTES + ((CG * XP * 4 + 15) & ~15) + XSLACK + ADJ_BYTES;
   const long Pout = (long)a.T_out * V, Psrc = (long)a.T_src * V;
 
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -487,8 +490,8 @@ __global__ void __launch_bounds__((NWC + NWP) * 64, (NWC + NWP) / 4) wgrad_pc_ke
     if (XP > FTV)                                // the pad element of a row is read (times zero) by the chain
       for (int e = threadIdx.x - NWC * 64; e < 2 * CG; e += NTP)
         reinterpret_cast<float*>(smem + (e / CG) * BUF_BYTES + DY_BYTES)[(e % CG) * XP + FTV] = 0.f;
-    {                                            // the alignment gap behind the last x row is read too (times zero)
-      const int gap = (((CG * XP * 4 + 15) & ~15) - CG * XP * 4) / 4;
+    {                                            // the alignment gap (+ slack) behind the last x row is read too (times zero)
+      const int gap = (((CG * XP * 4 + 15) & ~15) - CG * XP * 4 + XSLACK) / 4;
       const int e = threadIdx.x - NWC * 64;
       if (e < 2 * gap) reinterpret_cast<float*>(smem + (e / max(gap, 1)) * BUF_BYTES + DY_BYTES)[CG * XP + e % max(gap, 1)] = 0.f;
     }
@@ -777,7 +780,7 @@ WcGeom wc_geom_pc(int N, int M, int C, int V, int T_out, bool bch = false, int p
   g.nmb = (M + BM - 1) / BM;
   g.XP = (FT * V) | 1;
   g.smem_bytes = 2 * ((size_t)planes * FT * 4 * (BM + 1) * 16 + (((size_t)CG * g.XP * 4 + 15) & ~(size_t)15) +
-                      (AGG ? (bch ? (size_t)3 * planes * 2 * 2 * 32 * 16 : (size_t)3 * 32 * 32 * 4) : 0)) + 32;
+                      (AGG ? (bch ? (size_t)3 * planes * 2 * 2 * 32 * 16 + 128 : (size_t)3 * 32 * 32 * 4) : 0)) + 32;
   g.grid_x = g.nmb * g.ncg;
   const int pairs = N * g.ntiles;
   int want = 256 / g.grid_x;                   // one 12-wave workgroup per CU
