@@ -60,15 +60,31 @@ __global__ void __launch_bounds__(256) tv_transpose_kernel(const TrArgs a) {
   const int pitch = TT * a.V + 4;                // row pitch in LDS (a load instruction never crosses a row)
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int npiece = (len + 63) >> 6;            // 64-float pieces per row
-  for (int p = wave; p < RB * npiece; p += 4) {  // wave-uniform piece -> (row, offset)
-    const int r = p / npiece, e0 = (p - r * npiece) * 64;
-    if (r0 + r < a.R) {
-      const float* src = a.in + (((long)n * a.R + r0 + r) * a.T + t0) * a.V + e0;
-      const int e = min(lane, len - 1 - e0);     // the ragged last piece re-reads its last element (never used)
-      typedef const __attribute__((address_space(1))) void* gptr_t;
-      typedef __attribute__((address_space(3))) void* lptr_t;
-      __builtin_amdgcn_global_load_lds((gptr_t)(src + e), (lptr_t)(tile + r * pitch + e0), 4, 0, 0);
+  typedef const __attribute__((address_space(1))) void* gptr_t;
+  typedef __attribute__((address_space(3))) void* lptr_t;
+  // 16 bytes per lane (1 KB per wave-instruction) where the source rows allow it: T*V and the tile's length multiples of 4
+  // floats and a 16-byte aligned tensor (workgroup-uniform); 4 bytes per lane otherwise
+  const bool wide = ((a.T * a.V) & 3) == 0 && (len & 3) == 0 && len > 0 && ((reinterpret_cast<unsigned long>(a.in) & 15) == 0);
+  if (wide) {
+    const int npiece = (len + 255) >> 8;         // 256-float pieces per row
+    for (int p = wave; p < RB * npiece; p += 4) {
+      const int r = p / npiece, e0 = (p - r * npiece) * 256;
+      if (r0 + r < a.R) {
+        const float* src = a.in + (((long)n * a.R + r0 + r) * a.T + t0) * a.V + e0;
+        // (lanes past the row's end stay out: the destination of lane l is base + 16 l, and the next row starts there)
+        if (e0 + 4 * lane < len)
+          __builtin_amdgcn_global_load_lds((gptr_t)(src + 4 * lane), (lptr_t)(tile + r * pitch + e0), 16, 0, 0);
+      }
+    }
+  } else {
+    const int npiece = (len + 63) >> 6;          // 64-float pieces per row
+    for (int p = wave; p < RB * npiece; p += 4) {  // wave-uniform piece -> (row, offset)
+      const int r = p / npiece, e0 = (p - r * npiece) * 64;
+      if (r0 + r < a.R) {
+        const float* src = a.in + (((long)n * a.R + r0 + r) * a.T + t0) * a.V + e0;
+        const int e = min(lane, len - 1 - e0);   // the ragged last piece re-reads its last element (never used)
+        __builtin_amdgcn_global_load_lds((gptr_t)(src + e), (lptr_t)(tile + r * pitch + e0), 4, 0, 0);
+      }
     }
   }
   __syncthreads();                               // (drains the LDS-DMA: the compiler waits vmcnt(0) here)
