@@ -97,7 +97,9 @@ int agcn_bn_bwd_apply_ex(const float* part, int nrows, double count, float param
                          float* dgamma2, float* dbeta2, float* absmax1_out, int N, int C, int P, void* stream);
 /* the aggregate+project chain runs on f16x3 too (agcn_chain_mode): x_absmax = max |x| (agcn_bn_act_fwd_ex of the previous
  * unit), dy_absmax = max |dy| (agcn_bn_bwd_apply_ex), dtp_absmax = max |dtp|; any of them NULL: a streaming pass inside.
- * agcn_gcn_aggregate_project_bwd_data_ex covers both backward-data forms: dtp NULL = the plain one, else the fused one. */
+ * agcn_gcn_aggregate_project_bwd_data_ex covers both backward-data forms: dtp NULL = the plain one, else the fused one.
+ * agcn_gcn_dadj_ex: dy_absmax for the projection H = Wd^T dy, x_absmax (the forward's max |x|) for the reduction of H
+ * against x, both on f16x3; NULL: a streaming pass inside (same bits either way). */
 int agcn_gcn_aggregate_project_fwd_ex(const float* x, const float* adj, const float* wcat, const float* bias, float* y,
                                       float* stats_part, void* workspace, size_t workspace_bytes, int N, int C, int Cout,
                                       int T, int V, const float* x_absmax, void* stream);
@@ -112,7 +114,9 @@ int agcn_gcn_dadj_ex(const float* dy, const float* wcat, const float* x, float* 
 int agcn_adjacency_bwd_scores_ex(const float* tp, const float* dS, float* dtp, float* dbpart, void* scratch, float* db,
                                  float* dtp_absmax_out, int N, int Ci, int T, int V, void* stream);
 /* weight gradients: with BOTH operand maxima given the tap-free gradients (1x1, stride 1, Cin a multiple of 64; the
- * projection gradient with C a multiple of 64) run on f16x3; NULL: bf16x6 as the plain entry points (no pass inside) */
+ * projection gradient with C a multiple of 64, its aggregation included) run on f16x3; NULL: bf16x6 as the plain entry
+ * points (no pass inside).  The 9-tap gradient (rows and channels multiples of 64) runs on f16x3 either way: its
+ * transposing pre-pass writes the range-scaled fp16 planes and takes a missing maximum with a reduction pass of its own. */
 int agcn_conv_bwd_weight_ex(const float* dy, const float* x, float* dw, void* workspace, size_t workspace_bytes, int N,
                             int Cin, int Cout, int T, int V, int taps, int stride, const float* dy_absmax,
                             const float* x_absmax, void* stream);
