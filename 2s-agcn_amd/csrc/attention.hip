@@ -93,11 +93,13 @@ struct ApplyArgs {
   float* out;
   long total;
   int C, T, V, bwd;
+  unsigned* amax;      // optional: receives max |out| (bit pattern of a non-negative float), zeroed by the launcher
 };
 
 __global__ void __launch_bounds__(256) stc_apply_kernel(const ApplyArgs a) {
   const long i4 = ((long)blockIdx.x * 256 + threadIdx.x) * 4;
-  if (i4 >= a.total) return;
+  unsigned mx = 0;
+  if (i4 < a.total) {
   const int P = a.T * a.V;
   const f32x4 x = *reinterpret_cast<const f32x4*>(a.y + i4);
   f32x4 o;
@@ -117,6 +119,25 @@ __global__ void __launch_bounds__(256) stc_apply_kernel(const ApplyArgs a) {
     }
   }
   *reinterpret_cast<f32x4*>(a.out + i4) = o;
+  if (a.amax) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const float ok = o[k];
+      mx = max(mx, __float_as_uint(ok) & 0x7fffffffu);
+    }
+  }
+  }
+  if (a.amax) {                          // one atomic per workgroup at most, none once the running maximum has passed it
+    __shared__ unsigned wmax[4];
+#pragma unroll
+    for (int k = 32; k >= 1; k >>= 1) mx = max(mx, (unsigned)__shfl_xor((int)mx, k));
+    if ((threadIdx.x & 63) == 0) wmax[threadIdx.x >> 6] = mx;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      const unsigned m = max(max(wmax[0], wmax[1]), max(wmax[2], wmax[3]));
+      if (m > __hip_atomic_load(a.amax, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(a.amax, m);
+    }
+  }
 }
 
 }  // namespace
@@ -142,14 +163,22 @@ int agcn_stc_row_reduce(const float* y, const float* g, const float* wv, const f
 }
 
 // out = y * a_s[n,v] * a_t[n,t] * a_c[n,c]      (a_* = 1 + sigmoid gate); N*C*T*V % 4 == 0
+int agcn_stc_apply_ex(const float* y, const float* a_s, const float* a_t, const float* a_c, float* out, float* absmax_out,
+                      int N, int C, int T, int V, void* stream);
 int agcn_stc_apply(const float* y, const float* a_s, const float* a_t, const float* a_c, float* out, int N, int C, int T,
                    int V, void* stream) {
+  return agcn_stc_apply_ex(y, a_s, a_t, a_c, out, nullptr, N, C, T, V, stream);
+}
+// absmax_out (optional, 4 bytes): receives max |out| for the f16x3 temporal convolution that reads the gated tensor next
+int agcn_stc_apply_ex(const float* y, const float* a_s, const float* a_t, const float* a_c, float* out, float* absmax_out,
+                      int N, int C, int T, int V, void* stream) {
   if (!y || !a_s || !a_t || !a_c || !out || N <= 0 || C <= 0 || T <= 0 || V <= 0) return AGCN_ERR_ARG;
   const long total = (long)N * C * T * V;
   if (total % 4) return AGCN_ERR_UNSUPPORTED;
+  if (absmax_out && hipMemsetAsync(absmax_out, 0, 4, (hipStream_t)stream) != hipSuccess) return AGCN_ERR_ARG;
   ApplyArgs a;
   a.y = y; a.as = a_s; a.at = a_t; a.ac = a_c; a.dmv = nullptr; a.dms = nullptr; a.out = out; a.total = total;
-  a.C = C; a.T = T; a.V = V; a.bwd = 0;
+  a.C = C; a.T = T; a.V = V; a.bwd = 0; a.amax = reinterpret_cast<unsigned*>(absmax_out);
   hipLaunchKernelGGL(stc_apply_kernel, dim3((unsigned)((total / 4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a);
   return agcn_check_launch();
 }
@@ -162,7 +191,7 @@ int agcn_stc_bwd_apply(const float* dout, const float* a_s, const float* a_t, co
   if (total % 4) return AGCN_ERR_UNSUPPORTED;
   ApplyArgs a;
   a.y = dout; a.as = a_s; a.at = a_t; a.ac = a_c; a.dmv = dmv; a.dms = dms; a.out = dy; a.total = total;
-  a.C = C; a.T = T; a.V = V; a.bwd = 1;
+  a.C = C; a.T = T; a.V = V; a.bwd = 1; a.amax = nullptr;
   hipLaunchKernelGGL(stc_apply_kernel, dim3((unsigned)((total / 4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a);
   return agcn_check_launch();
 }

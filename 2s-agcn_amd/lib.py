@@ -80,6 +80,7 @@ SIGNATURES = {
     "agcn_bn_bwd_apply": (_I, [_P, _I, _D, _F, _P, _P, _I] + [_P] * 15 + [_I, _I, _I, _P]),
     "agcn_stc_row_reduce": (_I, [_P, _P, _P, _P, _I, _P, _P, _F, _F, _I, _I, _I, _I, _P]),
     "agcn_stc_apply": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
+    "agcn_stc_apply_ex": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
     "agcn_stc_bwd_apply": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
     "agcn_data_bn_stats": (_I, [_P, _P, _I, _I, _I, _I, _I, _P]),
     "agcn_data_bn_apply": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),

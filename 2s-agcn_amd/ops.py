@@ -524,8 +524,11 @@ class STCAttentionFunction(torch.autograd.Function):
         mv1, _ = stc_row_reduce(y, wv=a_s, want_t=True, scale_t=1.0 / V)                 # mean_v y*(1+se_s)
         _, a_t, a_c, m_c, h = STCAttentionFunction._gates(m_s, mv1, *par, a_s=a_s)
         out = torch.empty_like(y)
-        _lib.check(_L().agcn_stc_apply(_lib.ptr(y), _lib.ptr(a_s), _lib.ptr(a_t), _lib.ptr(a_c), _lib.ptr(out), N, C, T,
-                                       V, _lib.stream()), "agcn_stc_apply")
+        # the gated tensor feeds the f16x3 temporal convolution (and its weight gradient): leave its maximum behind
+        o_amax = _empty((1,), y) if fused_amax_enabled() else None
+        _lib.check(_L().agcn_stc_apply_ex(_lib.ptr(y), _lib.ptr(a_s), _lib.ptr(a_t), _lib.ptr(a_c), _lib.ptr(out),
+                                          _lib.ptr(o_amax), N, C, T, V, _lib.stream()), "agcn_stc_apply")
+        _note_out_amax(out, o_amax)
         ctx.save_for_backward(y, m_s, mv1, a_s, a_t, a_c, m_c, h, *par)
         return out
 
@@ -879,6 +882,8 @@ def tcn_forward(c, g, w, b, bn, stride, res_x, res, relu, training, sync=None):
     (w, b, bn_w, bn_b, bn_rm, bn_rv) for the unit_tcn(kernel_size=1, stride) residual."""
     N, C, T, V = g.shape
     g_amax = getattr(c, 'g_amax', None) if getattr(c, 'g_out', None) is g else None   # only for the tensor it describes
+    if g_amax is None and getattr(c, 'g_out', None) is None:
+        g_amax = _take_out_amax(g)       # stand-alone unit_tcn (AAGCN): the producer of g (attention gates / unit_gcn) noted it
     zpre, st = conv_fwd(g, w, b, stride, want_stats=training, x_amax=g_amax)
     To = zpre.shape[2]
     count = N * To * V
@@ -1063,6 +1068,7 @@ class UnitGCNFunction(torch.autograd.Function):
                           alpha, adaptive, sync, need_bwd=any(ctx.needs_input_grad))
         ctx.c, ctx.training = c, training
         ctx.has_down = down is not None
+        _note_out_amax(out, getattr(c, 'g_amax', None))     # stand-alone node: a unit_tcn may read this tensor next
         return out
 
     @staticmethod

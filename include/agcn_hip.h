@@ -269,6 +269,9 @@ int agcn_stc_row_reduce(const float* y, const float* g, const float* wv, const f
                         float* out_v, float scale_t, float scale_v, int N, int C, int T, int V, void* stream);
 int agcn_stc_apply(const float* y, const float* a_s, const float* a_t, const float* a_c, float* out, int N, int C, int T,
                    int V, void* stream);
+/* same; absmax_out (optional, 4 bytes) receives max |out| for the f16x3 temporal convolution that reads the gated tensor */
+int agcn_stc_apply_ex(const float* y, const float* a_s, const float* a_t, const float* a_c, float* out, float* absmax_out,
+                      int N, int C, int T, int V, void* stream);
 int agcn_stc_bwd_apply(const float* dout, const float* a_s, const float* a_t, const float* a_c, const float* dmv,
                        const float* dms, float* dy, int N, int C, int T, int V, void* stream);
 
